@@ -1,0 +1,143 @@
+/*
+ * teeflow.h -- C ABI of libteeflow_hip.so, the MI355X (gfx950) dense optical-flow engine.
+ *
+ * Drop-in boundary.  The reference is pure Python; on its hot path it holds a
+ * cv2.DenseOpticalFlow object and calls three things on it.  Each entry point below names the
+ * reference interface it replaces (paths relative to /root/reference):
+ *
+ *   cv2.optflow.createOptFlow_DualTVL1()            optical_flow/calculate_optical_flow.py:577   -> tf_create
+ *   cv2.cuda.OpticalFlowDual_TVL1.create()          optical_flow/calculate_optical_flow.py:575   -> tf_create
+ *   OF_model.setLambda(config.lambda_value)         optical_flow/calculate_optical_flow.py:578   -> tf_set_param
+ *   OF_model.calc(I0, I1, None)                     optical_flow/calculate_optical_flow.py:642   -> tf_calc_pair
+ *   GpuMat.upload x2 + calc + download              optical_flow/calculate_optical_flow.py:634-639 -> tf_calc_pair
+ *   the per-frame-pair loop of process_video()      optical_flow/calculate_optical_flow.py:584-600 -> tf_calc_seq
+ *   (batch of independent pairs, BASELINE config 3)                                              -> tf_calc_pairs
+ *
+ * Plain pointers and sizes only; no torch / numpy types.  The library owns all device memory and its
+ * HIP stream.  One handle per device; a handle is NOT re-entrant (mirrors the cv2 object, which the
+ * reference also reuses sequentially from one thread).  All functions return TF_OK (0) or an error
+ * code; tf_last_error() gives the message (the Python layer raises OpticalFlowCalculationError,
+ * reference optical_flow/exceptions.py:26-28).
+ *
+ * Flow convention (same as cv2): flow[y][x][0] = x displacement, flow[y][x][1] = y displacement, in
+ * pixels per frame, such that I1(x + u, y + v) ~= I0(x, y).
+ */
+#ifndef TEEFLOW_H
+#define TEEFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_ABI_VERSION 1
+
+enum {
+    TF_OK = 0,
+    TF_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, ... (cv2 would raise cv2.error) */
+    TF_ERR_UNSUPPORTED = 2,   /* parameter combination the engine does not implement */
+    TF_ERR_HIP = 3,           /* a HIP runtime call failed; message in tf_last_error */
+    TF_ERR_NOMEM = 4,
+    TF_ERR_NO_DEVICE = 5      /* no gfx950 device visible: there is NO CPU fallback */
+};
+
+enum { TF_ALGO_TVL1 = 0, TF_ALGO_DEEPFLOW = 1 /* reserved, SURVEY.md row a6 */ };
+
+/* keys for tf_set_param / tf_get_param: the 12 cv2.DualTVL1OpticalFlow setters */
+enum {
+    TF_PARAM_TAU = 0, TF_PARAM_LAMBDA = 1, TF_PARAM_THETA = 2, TF_PARAM_NSCALES = 3,
+    TF_PARAM_WARPS = 4, TF_PARAM_EPSILON = 5, TF_PARAM_INNER_ITERATIONS = 6,
+    TF_PARAM_OUTER_ITERATIONS = 7, TF_PARAM_SCALE_STEP = 8, TF_PARAM_GAMMA = 9,
+    TF_PARAM_MEDIAN_FILTERING = 10, TF_PARAM_USE_INITIAL_FLOW = 11,
+    TF_PARAM__COUNT = 12
+};
+
+typedef struct tf_params {
+    double tau, lambda, theta, epsilon, scale_step, gamma;
+    int nscales, warps, inner_iterations, outer_iterations, median_filtering, use_initial_flow;
+    int algo;        /* TF_ALGO_* */
+    int max_batch;   /* pairs resident per sub-batch (0 = default 128) */
+} tf_params;
+
+/* Filled by every tf_calc_* call (may be NULL). Times are milliseconds (HIP events on the handle's stream). */
+typedef struct tf_stats {
+    int n_pairs;               /* pairs solved by the call */
+    int nscales_used;          /* pyramid levels actually used (<= nscales) */
+    int warps;
+    int reserved0;
+    double ms_total;           /* whole call, host clock */
+    double ms_h2d, ms_device, ms_d2h;
+    /* dominant kernel (tvl1_iter): launches, summed duration (only when profiling is on) and bytes */
+    unsigned long long iter_launches;
+    unsigned long long iter_pair_steps;    /* sum over launches of pairs that actually iterated */
+    double iter_ms;                        /* sum of tvl1_iter launch durations (tf_set_profile(h,1)) */
+    double iter_bytes;                     /* algorithmic bytes of all executed pair-iterations (60 B/px) */
+    double total_bytes;                    /* algorithmic bytes of the whole solve */
+    unsigned long long inner_iters_total;  /* sum over pairs/levels/warps of executed inner iterations */
+    unsigned long long outer_iters_total;  /* ... of executed outer iterations (= median passes) */
+} tf_stats;
+
+typedef struct tf_handle tf_handle;
+
+/* cv2 defaults: tau .25 lambda .15 theta .3 nscales 5 warps 5 eps .01 inner 30 outer 10 step .8 gamma 0 median 5 */
+int tf_default_params(tf_params* p);
+
+/* replaces createOptFlow_DualTVL1() / cuda.OpticalFlowDual_TVL1.create()  (calculate_optical_flow.py:575,577) */
+int tf_create(const tf_params* p, int device_id, tf_handle** out);
+void tf_destroy(tf_handle* h);
+
+/* replaces OF_model.setLambda(...) and the 11 sibling setters / getters  (calculate_optical_flow.py:578) */
+int tf_set_param(tf_handle* h, int key, double value);
+int tf_get_param(tf_handle* h, int key, double* value);
+
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own. NULL restores. */
+int tf_set_stream(tf_handle* h, void* hip_stream);
+/* 0 = off; 1 = bracket every tvl1_iter launch with HIP events so tf_stats.iter_ms is filled */
+int tf_set_profile(tf_handle* h, int level);
+
+/* replaces OF_model.calc(I0, I1, None)  (calculate_optical_flow.py:631,638,642).
+ * I0, I1: host uint8 [H][W] C-contiguous.  flow_out: host float32 [H][W][2]. */
+int tf_calc_pair(tf_handle* h, const uint8_t* I0, const uint8_t* I1, int H, int W, float* flow_out, tf_stats* st);
+
+/* replaces the sliding-window loop of process_video() (calculate_optical_flow.py:584-600):
+ * frames: host uint8 [N][H][W]; flow_out: host float32 [N-1][H][W][2] = flow(frame i -> frame i+1) * scale.
+ * (The caller duplicates the last field, reference :599.) */
+int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, tf_stats* st);
+
+/* B independent pairs (BASELINE.json config 3): I0s, I1s host uint8 [B][H][W]; flow_out float32 [B][H][W][2]. */
+int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st);
+
+/* Same, with every buffer already resident in this device's HBM (pointers are device pointers); work is
+ * enqueued on the handle's stream and the call returns after the stream has drained. */
+int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W,
+                         float scale, float* dflow_out, tf_stats* st);
+int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale,
+                       float* dflow_out, tf_stats* st);
+
+/* Executed iteration counts of the last call: int32 [n_pairs][nscales_used][warps][2] = (inner, outer).
+ * Returns the number of ints written (<= capacity) through *written. */
+int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written);
+
+/* message of the last failure on this handle (or of the last failed tf_create when h == NULL) */
+const char* tf_last_error(tf_handle* h);
+int tf_abi_version(void);
+int tf_device_count(void);
+
+/* ---- kernel-level test hooks (dense host arrays, one image; used by tests/ to compare each kernel
+ *      with the oracle bit for bit; not part of the drop-in surface) -------------------------------- */
+int tf_dbg_pyramid(tf_handle* h, const uint8_t* img, int H, int W, int level, float* out, int* ow, int* oh);
+int tf_dbg_resize(tf_handle* h, const float* src, int sw, int sh, float* dst, int dw, int dh,
+                  double inv_scale_x, double inv_scale_y, float mul);
+int tf_dbg_warp(tf_handle* h, const float* I0, const float* I1, const float* u1, const float* u2, int w, int hgt,
+                float* I1wx, float* I1wy, float* rho_c);
+int tf_dbg_median(tf_handle* h, const float* src, int w, int hgt, int ksize, float* dst);
+int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, const float* rho_c,
+                   float* u1, float* u2, float* p11, float* p12, float* p21, float* p22,
+                   int w, int hgt, int nsteps, int p_is_zero, unsigned long long* err_q);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEEFLOW_H */

@@ -1,0 +1,181 @@
+"""ctypes wrapper over oracle/libtvl1_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (tee_optical_flow_amd) never imports it and has no CPU fallback.
+
+See tvl1_oracle.c for what is restated (reference call sites
+/root/reference/optical_flow/calculate_optical_flow.py:577-578, 642) and for the
+"PARITY UNPINNED vs real OpenCV" statement.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtvl1_oracle.so")
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("tau", C.c_double), ("lambda_", C.c_double), ("theta", C.c_double),
+                ("epsilon", C.c_double), ("scale_step", C.c_double), ("gamma", C.c_double),
+                ("nscales", C.c_int), ("warps", C.c_int), ("inner_iterations", C.c_int),
+                ("outer_iterations", C.c_int), ("median_filtering", C.c_int),
+                ("use_initial_flow", C.c_int), ("err_mode", C.c_int)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "tvl1_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_resize_linear.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_scaled_size.argtypes = [C.c_int, C.c_double]
+        L.orc_scaled_size.restype = C.c_int
+        L.orc_centered_gradient.argtypes = [fp, C.c_int, C.c_int, fp, fp]
+        L.orc_bicubic_tab.argtypes = [fp]
+        L.orc_warp.argtypes = [fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.orc_remap_bicubic.argtypes = [fp, C.c_int, C.c_int, fp, fp, fp]
+        L.orc_median_blur.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_iterate.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int,
+                                  C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.orc_tvl1_calc.argtypes = [C.POINTER(OrcParams), u8p, u8p, C.c_int, C.c_int, fp, C.c_void_p]
+        L.orc_tvl1_calc.restype = C.c_int
+        L.orc_pyramid_level.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def default_params(**over):
+    p = OrcParams()
+    lib().orc_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, "lambda_" if k == "lambda" else k, v)
+    return p
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def resize_linear(src, dw, dh, inv_scale_x=None, inv_scale_y=None):
+    src = _f32(src)
+    sh, sw = src.shape
+    if inv_scale_x is None:
+        inv_scale_x = dw / sw
+    if inv_scale_y is None:
+        inv_scale_y = dh / sh
+    dst = np.empty((dh, dw), np.float32)
+    lib().orc_resize_linear(src, sw, sh, dst, dw, dh, float(inv_scale_x), float(inv_scale_y))
+    return dst
+
+
+def scaled_size(s, f):
+    return lib().orc_scaled_size(int(s), float(f))
+
+
+def centered_gradient(src):
+    src = _f32(src)
+    h, w = src.shape
+    dx = np.empty_like(src)
+    dy = np.empty_like(src)
+    lib().orc_centered_gradient(src, w, h, dx, dy)
+    return dx, dy
+
+
+def bicubic_tab():
+    t = np.empty((32, 4), np.float32)
+    lib().orc_bicubic_tab(t)
+    return t
+
+
+def remap_bicubic(src, mapx, mapy):
+    src = _f32(src)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    lib().orc_remap_bicubic(src, w, h, _f32(mapx), _f32(mapy), dst)
+    return dst
+
+
+def warp(I0, I1, u1, u2):
+    """One TV-L1 warp stage: returns (I1wx, I1wy, grad, rho_c)."""
+    I0, I1, u1, u2 = map(_f32, (I0, I1, u1, u2))
+    h, w = I0.shape
+    I1x, I1y = centered_gradient(I1)
+    outs = [np.empty_like(I0) for _ in range(4)]
+    lib().orc_warp(I0, I1, I1x, I1y, u1, u2, w, h, *outs)
+    return tuple(outs)
+
+
+def median_blur(src, ksize=5):
+    src = _f32(src)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    lib().orc_median_blur(src, w, h, int(ksize), dst)
+    return dst
+
+
+def iterate(I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p22, nsteps, lam=0.15, theta=0.3, tau=0.25):
+    """Run nsteps inner iterations; returns (u1,u2,p11,p12,p21,p22, err_q[uint64 nsteps])."""
+    c = [_f32(a) for a in (I1wx, I1wy, grad, rho_c)]
+    s = [_f32(a).copy() for a in (u1, u2, p11, p12, p21, p22)]
+    h, w = c[0].shape
+    err = np.zeros(nsteps, np.uint64)
+    lib().orc_iterate(*c, *s, w, h, float(lam), float(theta), float(tau), int(nsteps),
+                      err.ctypes.data_as(C.c_void_p))
+    return (*s, err)
+
+
+def tvl1_calc(I0, I1, params=None, return_iters=False):
+    """Full DualTVL1 on one uint8 pair -> float32 [H,W,2]."""
+    I0 = np.ascontiguousarray(I0, dtype=np.uint8)
+    I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+    assert I0.shape == I1.shape and I0.ndim == 2
+    p = params if params is not None else default_params()
+    h, w = I0.shape
+    flow = np.empty((h, w, 2), np.float32)
+    iters = np.zeros((p.nscales, max(p.warps, 1), 2), np.int32)
+    rc = lib().orc_tvl1_calc(C.byref(p), I0, I1, h, w, flow.reshape(-1), iters.ctypes.data_as(C.c_void_p))
+    if rc <= 0:
+        raise RuntimeError(f"orc_tvl1_calc failed rc={rc}")
+    if return_iters:
+        return flow, iters[:, :p.warps], rc
+    return flow
+
+
+def pyramid_level(img, level, scale_step=0.8):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    ow, oh = C.c_int(), C.c_int()
+    lib().orc_pyramid_level(img, h, w, float(scale_step), int(level), None, C.byref(ow), C.byref(oh))
+    out = np.empty((oh.value, ow.value), np.float32)
+    lib().orc_pyramid_level(img, h, w, float(scale_step), int(level), out.ctypes.data_as(C.c_void_p),
+                            C.byref(ow), C.byref(oh))
+    return out

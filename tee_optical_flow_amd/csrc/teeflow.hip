@@ -1,0 +1,764 @@
+// teeflow.hip -- host driver + C ABI (include/teeflow.h) of the MI355X DualTVL1 engine.
+//
+// Replaces, for the reference's hot path only, what cv2's DenseOpticalFlow object does behind
+// /root/reference/optical_flow/calculate_optical_flow.py:564-600, 627-642.  No CPU fallback: without a
+// gfx950 device tf_create fails with TF_ERR_NO_DEVICE.
+//
+// Execution model: a batch of B frame pairs advances in lock-step through
+//   pyramid -> for level (coarse..fine): for warp: k_warp, then [median every `inner` iterations,
+//   tvl1_iter] until each pair's own convergence test stops it.
+// The stop decision lives on the device (per-pair error slots, blocks of stopped pairs exit at once);
+// the host only learns "nobody is iterating any more" through small lagged probes, so it never
+// stalls the stream inside the iteration budget.
+#include "teeflow_kernels.hip.h"
+#include "../../include/teeflow.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#define TF_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int MAXLEV = 64;
+constexpr int PROBE_RING = 32;
+constexpr int PROBE_LAG = 2;          // host runs at most this many probes ahead of the GPU's answers
+constexpr int DEFAULT_MAX_BATCH = 128;
+
+thread_local std::string g_create_error;
+
+struct ProfEv { hipEvent_t a, b; };
+
+}  // namespace
+
+struct tf_handle {
+    tf_params P;
+    int dev = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int profile = 0;
+    std::string err;
+    // geometry the buffers are allocated for
+    int H = 0, W = 0, cap = 0, nlev = 0;
+    double alloc_scale_step = 0; int alloc_nscales = 0;
+    Geom lv[MAXLEV];
+    float* pyr[MAXLEV] = {};
+    float *cwx = nullptr, *cwy = nullptr, *crho = nullptr;
+    StateBufs sb = {};
+    PairCtl* ctl = nullptr;
+    u64* errs = nullptr; int errstride = 0;
+    int* iters_dev = nullptr; size_t iters_cap = 0;
+    int* probe_dev = nullptr; int* probe_host = nullptr;
+    hipEvent_t probe_ev[PROBE_RING] = {};
+    unsigned probe_seq = 0;
+    float* tab = nullptr;
+    // staging for the host-pointer API
+    uint8_t* st_u8 = nullptr; size_t st_u8_bytes = 0;
+    float* st_flow = nullptr; size_t st_flow_bytes = 0;
+    hipEvent_t ev[4] = {};
+    // profiling of tvl1_iter launches
+    std::vector<ProfEv> prof_pool; size_t prof_used = 0;
+    // results of the last call
+    std::vector<int> last_iters; int last_pairs = 0, last_nlev = 0, last_warps = 0;
+    // per-call accumulators
+    unsigned long long iter_launches = 0;
+};
+
+namespace {
+
+int fail(tf_handle* h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPC(h, call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(h, e_ == hipErrorOutOfMemory ? TF_ERR_NOMEM : TF_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int cv_round_d(double v) { return (int)lrint(v); }   // saturate_cast<int>(double): nearest-even
+
+Geom make_geom(int w, int h)
+{
+    Geom g; g.w = w; g.h = h; g.pitch = round_up(w, 32); g.plane = (long long)g.pitch * h;
+    return g;
+}
+
+int validate_params(tf_handle* h, const tf_params& p)
+{
+    if (p.algo != TF_ALGO_TVL1) return fail(h, TF_ERR_UNSUPPORTED, "algo %d not implemented (only TF_ALGO_TVL1)", p.algo);
+    if (p.nscales < 1 || p.nscales > MAXLEV) return fail(h, TF_ERR_INVALID_ARG, "nscales must be in [1,%d], got %d", MAXLEV, p.nscales);
+    if (p.warps < 1) return fail(h, TF_ERR_INVALID_ARG, "warps must be >= 1, got %d", p.warps);
+    if (p.inner_iterations < 1 || p.outer_iterations < 1)
+        return fail(h, TF_ERR_INVALID_ARG, "inner/outer iterations must be >= 1, got %d/%d", p.inner_iterations, p.outer_iterations);
+    if ((long long)p.inner_iterations * p.outer_iterations > 100000)
+        return fail(h, TF_ERR_INVALID_ARG, "inner*outer iterations too large");
+    if (p.median_filtering != 1 && p.median_filtering != 3 && p.median_filtering != 5)
+        return fail(h, TF_ERR_UNSUPPORTED, "medianFiltering must be 1, 3 or 5 (cv::medianBlur on CV_32F), got %d", p.median_filtering);
+    if (p.gamma != 0.0) return fail(h, TF_ERR_UNSUPPORTED, "gamma != 0 (illumination term u3) is not implemented");
+    if (p.use_initial_flow) return fail(h, TF_ERR_UNSUPPORTED, "useInitialFlow is not implemented");
+    if (!(p.scale_step > 0.0 && p.scale_step < 1.0)) return fail(h, TF_ERR_INVALID_ARG, "scaleStep must be in (0,1), got %g", p.scale_step);
+    if (!(p.theta > 0.0) || !(p.tau > 0.0) || !(p.lambda > 0.0) || !(p.epsilon >= 0.0))
+        return fail(h, TF_ERR_INVALID_ARG, "tau, lambda, theta must be > 0 and epsilon >= 0");
+    return TF_OK;
+}
+
+void free_buffers(tf_handle* h)
+{
+    auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    for (int l = 0; l < MAXLEV; ++l) F(h->pyr[l]);
+    F(h->cwx); F(h->cwy); F(h->crho);
+    for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
+    F(h->ctl); F(h->errs); F(h->iters_dev);
+    F(h->st_u8); F(h->st_flow);
+    h->st_u8_bytes = h->st_flow_bytes = 0;
+    h->H = h->W = h->cap = h->nlev = 0; h->iters_cap = 0;
+}
+
+// pyramid geometry of DualTVL1::calc: dsize = cvRound(size*scaleStep); stop before a level < 16 px
+int compute_levels(const tf_params& P, int H, int W, Geom* lv)
+{
+    int n = 1;
+    lv[0] = make_geom(W, H);
+    for (int s = 1; s < P.nscales; ++s) {
+        const int w = cv_round_d(lv[s - 1].w * P.scale_step), hh = cv_round_d(lv[s - 1].h * P.scale_step);
+        if (w < 16 || hh < 16) break;
+        lv[s] = make_geom(w, hh);
+        n = s + 1;
+    }
+    return n;
+}
+
+int ensure_alloc(tf_handle* h, int H, int W, int B)
+{
+    const int want_cap = B < (h->P.max_batch > 0 ? h->P.max_batch : DEFAULT_MAX_BATCH) ? B : (h->P.max_batch > 0 ? h->P.max_batch : DEFAULT_MAX_BATCH);
+    const int total = h->P.inner_iterations * h->P.outer_iterations;
+    if (h->H == H && h->W == W && h->cap >= want_cap && h->alloc_scale_step == h->P.scale_step &&
+        h->alloc_nscales == h->P.nscales && h->errstride >= total &&
+        h->iters_cap >= (size_t)h->cap * (size_t)h->nlev * (size_t)h->P.warps * 2)
+        return TF_OK;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    free_buffers(h);
+    h->nlev = compute_levels(h->P, H, W, h->lv);
+    const size_t cap = (size_t)want_cap, fcap = 2 * cap;
+    for (int l = 0; l < h->nlev; ++l) HIPC(h, hipMalloc(&h->pyr[l], fcap * h->lv[l].plane * sizeof(float)));
+    const size_t pl = (size_t)h->lv[0].plane * cap * sizeof(float);
+    HIPC(h, hipMalloc(&h->cwx, pl)); HIPC(h, hipMalloc(&h->cwy, pl)); HIPC(h, hipMalloc(&h->crho, pl));
+    for (int k = 0; k < 2; ++k) {
+        HIPC(h, hipMalloc(&h->sb.u1[k], pl)); HIPC(h, hipMalloc(&h->sb.u2[k], pl));
+        HIPC(h, hipMalloc(&h->sb.p11[k], pl)); HIPC(h, hipMalloc(&h->sb.p12[k], pl));
+        HIPC(h, hipMalloc(&h->sb.p21[k], pl)); HIPC(h, hipMalloc(&h->sb.p22[k], pl));
+    }
+    HIPC(h, hipMalloc(&h->ctl, cap * sizeof(PairCtl)));
+    h->errstride = total;
+    HIPC(h, hipMalloc(&h->errs, cap * (size_t)h->errstride * sizeof(u64)));
+    h->iters_cap = cap * (size_t)h->nlev * (size_t)h->P.warps * 2;
+    HIPC(h, hipMalloc(&h->iters_dev, h->iters_cap * sizeof(int)));
+    h->H = H; h->W = W; h->cap = want_cap;
+    h->alloc_scale_step = h->P.scale_step; h->alloc_nscales = h->P.nscales;
+    return TF_OK;
+}
+
+int ensure_staging(tf_handle* h, size_t u8_bytes, size_t flow_bytes)
+{
+    if (h->st_u8_bytes < u8_bytes) {
+        if (h->st_u8) (void)hipFree(h->st_u8);
+        h->st_u8 = nullptr; h->st_u8_bytes = 0;
+        HIPC(h, hipMalloc(&h->st_u8, u8_bytes)); h->st_u8_bytes = u8_bytes;
+    }
+    if (h->st_flow_bytes < flow_bytes) {
+        if (h->st_flow) (void)hipFree(h->st_flow);
+        h->st_flow = nullptr; h->st_flow_bytes = 0;
+        HIPC(h, hipMalloc(&h->st_flow, flow_bytes)); h->st_flow_bytes = flow_bytes;
+    }
+    return TF_OK;
+}
+
+inline dim3 grid64x4(const Geom& g, int z) { return dim3((g.w + 63) / 64, (g.h + 3) / 4, z); }
+
+struct StageTotals {
+    double iter_bytes = 0, total_bytes = 0;
+};
+
+// one (level, warp) stage for pairs [0,B)
+int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
+{
+    const tf_params& P = h->P;
+    const Geom g = h->lv[l];
+    const int inner = P.inner_iterations, total = P.inner_iterations * P.outer_iterations;
+    const float thr_f = (float)(P.epsilon * P.epsilon * (double)(g.w * g.h));
+    const double thr_q = (double)thr_f * 1073741824.0;
+    hipStream_t s = h->stream;
+
+    WarpArgs wa;
+    wa.pyr = h->pyr[l]; wa.off0 = off0; wa.off1 = off1; wa.sb = h->sb; wa.ctl = h->ctl; wa.tab = h->tab;
+    wa.wx = h->cwx; wa.wy = h->cwy; wa.rho = h->crho; wa.g = g;
+    hipLaunchKernelGGL(k_warp, grid64x4(g, B), dim3(256), 0, s, wa);
+    HIPC(h, hipMemsetAsync(h->errs, 0, (size_t)B * h->errstride * sizeof(u64), s));
+
+    IterArgs ia;
+    ia.wx = h->cwx; ia.wy = h->cwy; ia.rho = h->crho; ia.sb = h->sb; ia.ctl = h->ctl; ia.err = h->errs;
+    ia.errstride = h->errstride; ia.thr_q = thr_q; ia.g = g;
+    ia.l_t = (float)(P.lambda * P.theta); ia.theta = (float)P.theta; ia.taut = (float)(P.tau / P.theta);
+    MedArgs ma;
+    ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
+
+    const dim3 gi((g.w + IT_OW - 1) / IT_OW, (g.h + IT_OH - 1) / IT_OH, B);
+    const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
+    // probe cadence: every iteration for large batches (a probe costs ~a few us of stream time),
+    // sparser when one iteration itself is only a few us
+    const double est_iter_us = (double)B * g.w * g.h * 60.0 / 4.0e6;
+    const int cadence = est_iter_us >= 100.0 ? 1 : (est_iter_us >= 25.0 ? 2 : 4);
+
+    std::deque<unsigned> pending;
+    int utog = 0, ptog = 0;
+    bool stop = false;
+    for (int it = 0; it < total && !stop;) {
+        if (it % inner == 0 && P.median_filtering > 1) {
+            ma.it = it; ma.utog = utog;
+            if (P.median_filtering == 5) hipLaunchKernelGGL(k_median<5>, gm, dim3(256), 0, s, ma);
+            else hipLaunchKernelGGL(k_median<3>, gm, dim3(256), 0, s, ma);
+            ++utog;
+        }
+        ia.it = it; ia.utog = utog; ia.ptog = ptog; ia.pzero = (wi == 0 && it == 0) ? 1 : 0;
+        if (h->profile) {
+            if (h->prof_used == h->prof_pool.size()) {
+                ProfEv pe;
+                HIPC(h, hipEventCreate(&pe.a)); HIPC(h, hipEventCreate(&pe.b));
+                h->prof_pool.push_back(pe);
+            }
+            ProfEv& pe = h->prof_pool[h->prof_used++];
+            HIPC(h, hipEventRecord(pe.a, s));
+            hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, s, ia);
+            HIPC(h, hipEventRecord(pe.b, s));
+        } else {
+            hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, s, ia);
+        }
+        ++h->iter_launches;
+        ++utog; ++ptog; ++it;
+        if (it < total && it % cadence == 0) {
+            const unsigned slot = h->probe_seq++ % PROBE_RING;
+            hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), 0, s, h->errs, h->errstride, B, it, thr_q, h->probe_dev + slot);
+            HIPC(h, hipMemcpyAsync(h->probe_host + slot, h->probe_dev + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPC(h, hipEventRecord(h->probe_ev[slot], s));
+            pending.push_back(slot);
+        }
+        while (!pending.empty()) {
+            const unsigned slot = pending.front();
+            if ((int)pending.size() > PROBE_LAG) HIPC(h, hipEventSynchronize(h->probe_ev[slot]));
+            else {
+                hipError_t qe = hipEventQuery(h->probe_ev[slot]);
+                if (qe == hipErrorNotReady) break;
+                if (qe != hipSuccess) return fail(h, TF_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(qe));
+            }
+            pending.pop_front();
+            if (h->probe_host[slot] == 0) { stop = true; break; }
+        }
+    }
+    // any probe still in flight must land before its ring slot can be reused
+    if (!pending.empty()) HIPC(h, hipEventSynchronize(h->probe_ev[pending.back()]));
+    hipLaunchKernelGGL(k_stage_end, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
+                       total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
+    return TF_OK;
+}
+
+// Solve B pairs whose u8 frames are in device memory: frames[F][H][W], pair b = (off0+b, off1+b).
+int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0, int off1, float scale, float* dflow)
+{
+    const tf_params& P = h->P;
+    hipStream_t s = h->stream;
+    const Geom g0 = h->lv[0];
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
+    for (int l = 1; l < h->nlev; ++l) {
+        const double sc = 1.0 / P.scale_step;   // resize(src, Size(), fx, fy): scale = 1/fx
+        hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc);
+    }
+    const int L = h->nlev - 1;
+    hipLaunchKernelGGL(k_ctl_set, dim3((B + 255) / 256), dim3(256), 0, s, h->ctl, B, 0);
+    HIPC(h, hipMemsetAsync(h->sb.u1[0], 0, (size_t)B * h->lv[L].plane * sizeof(float), s));
+    HIPC(h, hipMemsetAsync(h->sb.u2[0], 0, (size_t)B * h->lv[L].plane * sizeof(float), s));
+    for (int l = L; l >= 0; --l) {
+        for (int wi = 0; wi < P.warps; ++wi) {
+            int rc = run_stage(h, l, wi, B, off0, off1);
+            if (rc) return rc;
+        }
+        if (l == 0) break;
+        const Geom gs = h->lv[l], gd = h->lv[l - 1];
+        // resize(u, size(I0s[s-1])): inv_scale = dsize/ssize, scale = 1/inv_scale
+        const double sx = 1.0 / ((double)gd.w / gs.w), sy = 1.0 / ((double)gd.h / gs.h);
+        hipLaunchKernelGGL(k_flow_up, grid64x4(gd, B), dim3(256), 0, s, h->sb, h->ctl, gs, gd, sx, sy, (float)(1 / P.scale_step));
+        hipLaunchKernelGGL(k_ctl_set, dim3((B + 255) / 256), dim3(256), 0, s, h->ctl, B, 1);
+    }
+    hipLaunchKernelGGL(k_output, grid64x4(g0, B), dim3(256), 0, s, h->sb, h->ctl, g0, scale, dflow);
+    HIPC(h, hipGetLastError());
+    return TF_OK;
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// algorithmic (compulsory) HBM bytes of one solved pair from its executed iteration counts
+void account_bytes(const tf_handle* h, const int* it /* [nlev][warps][2] */, double* iter_bytes, double* total_bytes,
+                   unsigned long long* n_in, unsigned long long* n_out)
+{
+    const int warps = h->P.warps;
+    double ib = 0, tb = 0;
+    for (int l = 0; l < h->nlev; ++l) {
+        const double px = (double)h->lv[l].w * h->lv[l].h;
+        for (int w = 0; w < warps; ++w) {
+            const int ni = it[(l * warps + w) * 2], no = it[(l * warps + w) * 2 + 1];
+            *n_in += ni; *n_out += no;
+            ib += px * 60.0 * ni;                                   // tvl1_iter: 9 reads + 6 writes
+            tb += px * (16.0 * (h->P.median_filtering > 1 ? no : 0)  // median: read+write u1,u2
+                        + 28.0);                                    // warp: read I0,I1,u1,u2; write I1wx,I1wy,rho_c
+        }
+        if (l > 0) tb += px * 8.0 + (double)h->lv[l - 1].w * h->lv[l - 1].h * 8.0;          // flow upsample
+        if (l > 0) tb += 2.0 * (px * 4.0 + (double)h->lv[l - 1].w * h->lv[l - 1].h * 4.0);  // pyramid level (2 frames)
+    }
+    tb += (double)h->lv[0].w * h->lv[0].h * (2.0 * (1 + 4) + 8.0 + 8.0);  // u8->f32 of 2 frames, output interleave
+    *iter_bytes += ib; *total_bytes += tb + ib;
+}
+
+enum Mode { MODE_PAIRS, MODE_SEQ };
+
+// common driver: device==true -> in/out pointers are device memory
+int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
+                float* flow_out, bool device, tf_stats* st)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!in0 || (mode == MODE_PAIRS && !in1) || !flow_out) return fail(h, TF_ERR_INVALID_ARG, "null image/flow pointer");
+    if (H < 1 || W < 1 || n_pairs < 1) return fail(h, TF_ERR_INVALID_ARG, "bad sizes: pairs=%d H=%d W=%d", n_pairs, H, W);
+    if ((long long)H * W > (1LL << 24)) return fail(h, TF_ERR_UNSUPPORTED, "images above 2^24 pixels are not supported");
+    int rc = validate_params(h, h->P);
+    if (rc) return rc;
+    HIPC(h, hipSetDevice(h->dev));
+    const double t0 = now_ms();
+    rc = ensure_alloc(h, H, W, n_pairs);
+    if (rc) return rc;
+    const size_t fpx = (size_t)H * W;
+    h->last_iters.assign((size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
+    h->last_pairs = n_pairs; h->last_nlev = h->nlev; h->last_warps = h->P.warps;
+    h->iter_launches = 0; h->prof_used = 0;
+    float ms_h2d = 0, ms_dev = 0, ms_d2h = 0;
+    if (!device) {
+        rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, (size_t)h->cap * fpx * 2 * sizeof(float));
+        if (rc) return rc;
+    }
+    for (int c0 = 0; c0 < n_pairs; c0 += h->cap) {
+        const int nb = n_pairs - c0 < h->cap ? n_pairs - c0 : h->cap;
+        const uint8_t* dfr; int F, off0, off1;
+        float* dfl;
+        HIPC(h, hipEventRecord(h->ev[0], h->stream));
+        if (mode == MODE_SEQ) {
+            F = nb + 1; off0 = 0; off1 = 1;
+            if (device) dfr = in0 + (size_t)c0 * fpx;
+            else { HIPC(h, hipMemcpyAsync(h->st_u8, in0 + (size_t)c0 * fpx, (size_t)F * fpx, hipMemcpyHostToDevice, h->stream)); dfr = h->st_u8; }
+        } else {
+            F = 2 * nb; off0 = 0; off1 = nb;
+            if (device && n_pairs <= h->cap && in1 == in0 + (size_t)n_pairs * fpx) dfr = in0;   // already [I0s|I1s] contiguous
+            else {
+                if (device) { rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, 0); if (rc) return rc; }
+                const hipMemcpyKind k = device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+                HIPC(h, hipMemcpyAsync(h->st_u8, in0 + (size_t)c0 * fpx, (size_t)nb * fpx, k, h->stream));
+                HIPC(h, hipMemcpyAsync(h->st_u8 + (size_t)nb * fpx, in1 + (size_t)c0 * fpx, (size_t)nb * fpx, k, h->stream));
+                dfr = h->st_u8;
+            }
+        }
+        dfl = device ? flow_out + (size_t)c0 * fpx * 2 : h->st_flow;
+        HIPC(h, hipEventRecord(h->ev[1], h->stream));
+        rc = solve_resident(h, dfr, F, nb, off0, off1, scale, dfl);
+        if (rc) return rc;
+        HIPC(h, hipEventRecord(h->ev[2], h->stream));
+        if (!device)
+            HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * fpx * 2, h->st_flow, (size_t)nb * fpx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipMemcpyAsync(h->last_iters.data() + (size_t)c0 * h->nlev * h->P.warps * 2, h->iters_dev,
+                               (size_t)nb * h->nlev * h->P.warps * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipEventRecord(h->ev[3], h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        float t;
+        HIPC(h, hipEventElapsedTime(&t, h->ev[0], h->ev[1])); ms_h2d += t;
+        HIPC(h, hipEventElapsedTime(&t, h->ev[1], h->ev[2])); ms_dev += t;
+        HIPC(h, hipEventElapsedTime(&t, h->ev[2], h->ev[3])); ms_d2h += t;
+    }
+    if (st) {
+        memset(st, 0, sizeof *st);
+        st->n_pairs = n_pairs; st->nscales_used = h->nlev; st->warps = h->P.warps;
+        st->ms_h2d = ms_h2d; st->ms_device = ms_dev; st->ms_d2h = ms_d2h;
+        st->iter_launches = h->iter_launches;
+        for (int b = 0; b < n_pairs; ++b)
+            account_bytes(h, h->last_iters.data() + (size_t)b * h->nlev * h->P.warps * 2, &st->iter_bytes, &st->total_bytes,
+                          &st->inner_iters_total, &st->outer_iters_total);
+        st->iter_pair_steps = st->inner_iters_total;
+        double ims = 0;
+        for (size_t i = 0; i < h->prof_used; ++i) {
+            float t = 0;
+            HIPC(h, hipEventElapsedTime(&t, h->prof_pool[i].a, h->prof_pool[i].b));
+            ims += t;
+        }
+        st->iter_ms = ims;
+        st->ms_total = now_ms() - t0;
+    }
+    return TF_OK;
+}
+
+// ---- small RAII device buffer for the tf_dbg_* hooks ---------------------------------------------
+struct DBuf {
+    float* p = nullptr;
+    ~DBuf() { if (p) (void)hipFree(p); }
+};
+
+int dbg_up(tf_handle* h, DBuf& d, const float* src, const Geom& g)
+{
+    HIPC(h, hipMalloc(&d.p, (size_t)g.plane * sizeof(float)));
+    HIPC(h, hipMemset(d.p, 0, (size_t)g.plane * sizeof(float)));
+    if (src) HIPC(h, hipMemcpy2D(d.p, (size_t)g.pitch * 4, src, (size_t)g.w * 4, (size_t)g.w * 4, g.h, hipMemcpyHostToDevice));
+    return TF_OK;
+}
+int dbg_down(tf_handle* h, float* dst, const float* d, const Geom& g)
+{
+    HIPC(h, hipMemcpy2D(dst, (size_t)g.w * 4, d, (size_t)g.pitch * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
+    return TF_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+TF_API int tf_abi_version(void) { return TF_ABI_VERSION; }
+
+TF_API int tf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+TF_API int tf_default_params(tf_params* p)
+{
+    if (!p) return TF_ERR_INVALID_ARG;
+    p->tau = 0.25; p->lambda = 0.15; p->theta = 0.3; p->epsilon = 0.01; p->scale_step = 0.8; p->gamma = 0.0;
+    p->nscales = 5; p->warps = 5; p->inner_iterations = 30; p->outer_iterations = 10; p->median_filtering = 5;
+    p->use_initial_flow = 0; p->algo = TF_ALGO_TVL1; p->max_batch = 0;
+    return TF_OK;
+}
+
+TF_API const char* tf_last_error(tf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
+{
+    if (!out) return fail(nullptr, TF_ERR_INVALID_ARG, "out == NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(nullptr, TF_ERR_NO_DEVICE, "no HIP device visible: libteeflow_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, TF_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, n);
+    tf_handle* h = new tf_handle();
+    if (p) h->P = *p; else tf_default_params(&h->P);
+    h->dev = device_id;
+    int rc = validate_params(h, h->P);
+    if (rc) { g_create_error = h->err; delete h; return rc; }
+    auto bail = [&](hipError_t e, const char* what) {
+        fail(nullptr, TF_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        tf_destroy(h);
+        return TF_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    h->stream = h->own_stream;
+    for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (auto& ev : h->probe_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc(&h->probe_dev, PROBE_RING * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipHostMalloc(&h->probe_host, PROBE_RING * sizeof(int))) != hipSuccess) return bail(e, "hipHostMalloc");
+    // bicubic coefficient table of cv::remap (interpolateCubic, A = -0.75, 1/32-px steps), float arithmetic
+    float tab[128];
+    {
+        const float A = -0.75f, scale = 1.f / 32;
+        for (int i = 0; i < 32; ++i) {
+            const float x = i * scale;
+            float* c = tab + i * 4;
+            c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+            c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+            c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+            c[3] = 1.f - c[0] - c[1] - c[2];
+        }
+    }
+    if ((e = hipMalloc(&h->tab, sizeof tab)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemcpy(h->tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    *out = h;
+    return TF_OK;
+}
+
+TF_API void tf_destroy(tf_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_buffers(h);
+    if (h->tab) (void)hipFree(h->tab);
+    if (h->probe_dev) (void)hipFree(h->probe_dev);
+    if (h->probe_host) (void)hipHostFree(h->probe_host);
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->probe_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& pe : h->prof_pool) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+TF_API int tf_set_param(tf_handle* h, int key, double v)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    tf_params p = h->P;
+    switch (key) {
+        case TF_PARAM_TAU: p.tau = v; break;
+        case TF_PARAM_LAMBDA: p.lambda = v; break;
+        case TF_PARAM_THETA: p.theta = v; break;
+        case TF_PARAM_NSCALES: p.nscales = (int)v; break;
+        case TF_PARAM_WARPS: p.warps = (int)v; break;
+        case TF_PARAM_EPSILON: p.epsilon = v; break;
+        case TF_PARAM_INNER_ITERATIONS: p.inner_iterations = (int)v; break;
+        case TF_PARAM_OUTER_ITERATIONS: p.outer_iterations = (int)v; break;
+        case TF_PARAM_SCALE_STEP: p.scale_step = v; break;
+        case TF_PARAM_GAMMA: p.gamma = v; break;
+        case TF_PARAM_MEDIAN_FILTERING: p.median_filtering = (int)v; break;
+        case TF_PARAM_USE_INITIAL_FLOW: p.use_initial_flow = v != 0.0; break;
+        default: return fail(h, TF_ERR_INVALID_ARG, "unknown parameter key %d", key);
+    }
+    int rc = validate_params(h, p);
+    if (rc) return rc;
+    h->P = p;
+    return TF_OK;
+}
+
+TF_API int tf_get_param(tf_handle* h, int key, double* v)
+{
+    if (!h || !v) return TF_ERR_INVALID_ARG;
+    const tf_params& p = h->P;
+    switch (key) {
+        case TF_PARAM_TAU: *v = p.tau; break;
+        case TF_PARAM_LAMBDA: *v = p.lambda; break;
+        case TF_PARAM_THETA: *v = p.theta; break;
+        case TF_PARAM_NSCALES: *v = p.nscales; break;
+        case TF_PARAM_WARPS: *v = p.warps; break;
+        case TF_PARAM_EPSILON: *v = p.epsilon; break;
+        case TF_PARAM_INNER_ITERATIONS: *v = p.inner_iterations; break;
+        case TF_PARAM_OUTER_ITERATIONS: *v = p.outer_iterations; break;
+        case TF_PARAM_SCALE_STEP: *v = p.scale_step; break;
+        case TF_PARAM_GAMMA: *v = p.gamma; break;
+        case TF_PARAM_MEDIAN_FILTERING: *v = p.median_filtering; break;
+        case TF_PARAM_USE_INITIAL_FLOW: *v = p.use_initial_flow; break;
+        default: return fail(h, TF_ERR_INVALID_ARG, "unknown parameter key %d", key);
+    }
+    return TF_OK;
+}
+
+TF_API int tf_set_stream(tf_handle* h, void* hip_stream)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return TF_OK;
+}
+
+TF_API int tf_set_profile(tf_handle* h, int level)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    h->profile = level;
+    return TF_OK;
+}
+
+TF_API int tf_calc_pair(tf_handle* h, const uint8_t* I0, const uint8_t* I1, int H, int W, float* flow_out, tf_stats* st)
+{
+    return calc_common(h, MODE_PAIRS, I0, I1, 1, H, W, 1.0f, flow_out, false, st);
+}
+
+TF_API int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st)
+{
+    return calc_common(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, st);
+}
+
+TF_API int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, tf_stats* st)
+{
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    return calc_common(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, false, st);
+}
+
+TF_API int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W, float scale,
+                                float* dflow_out, tf_stats* st)
+{
+    return calc_common(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, true, st);
+}
+
+TF_API int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, tf_stats* st)
+{
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    return calc_common(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, st);
+}
+
+TF_API int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written)
+{
+    if (!h || !out) return TF_ERR_INVALID_ARG;
+    const size_t n = h->last_iters.size() < capacity_ints ? h->last_iters.size() : capacity_ints;
+    memcpy(out, h->last_iters.data(), n * sizeof(int));
+    if (written) *written = n;
+    return TF_OK;
+}
+
+// ---- kernel-level hooks --------------------------------------------------------------------------
+TF_API int tf_dbg_resize(tf_handle* h, const float* src, int sw, int sh, float* dst, int dw, int dh,
+                         double inv_scale_x, double inv_scale_y, float mul)
+{
+    if (!h || !src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    const Geom gs = make_geom(sw, sh), gd = make_geom(dw, dh);
+    DBuf s, d;
+    int rc;
+    if ((rc = dbg_up(h, s, src, gs)) || (rc = dbg_up(h, d, nullptr, gd))) return rc;
+    hipLaunchKernelGGL(k_pyr_down, grid64x4(gd, 1), dim3(256), 0, h->stream, s.p, gs, d.p, gd, 1.0 / inv_scale_x, 1.0 / inv_scale_y);
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if ((rc = dbg_down(h, dst, d.p, gd))) return rc;
+    if (mul != 1.0f) for (size_t i = 0; i < (size_t)dw * dh; ++i) dst[i] *= mul;
+    return TF_OK;
+}
+
+TF_API int tf_dbg_pyramid(tf_handle* h, const uint8_t* img, int H, int W, int level, float* out, int* ow, int* oh)
+{
+    if (!h || !img || !ow || !oh || H < 1 || W < 1 || level < 0 || level >= MAXLEV) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    Geom g = make_geom(W, H);
+    uint8_t* d8 = nullptr;
+    HIPC(h, hipMalloc(&d8, (size_t)H * W));
+    HIPC(h, hipMemcpy(d8, img, (size_t)H * W, hipMemcpyHostToDevice));
+    DBuf cur;
+    int rc = dbg_up(h, cur, nullptr, g);
+    if (rc) { (void)hipFree(d8); return rc; }
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((g.w + 255) / 256, g.h, 1), dim3(256), 0, h->stream, d8, cur.p, g);
+    for (int s = 1; s <= level; ++s) {
+        Geom gn = make_geom(cv_round_d(g.w * h->P.scale_step), cv_round_d(g.h * h->P.scale_step));
+        if (gn.w < 1 || gn.h < 1) { (void)hipFree(d8); return fail(h, TF_ERR_INVALID_ARG, "pyramid level %d is empty", s); }
+        DBuf nxt;
+        if ((rc = dbg_up(h, nxt, nullptr, gn))) { (void)hipFree(d8); return rc; }
+        const double sc = 1.0 / h->P.scale_step;
+        hipLaunchKernelGGL(k_pyr_down, grid64x4(gn, 1), dim3(256), 0, h->stream, cur.p, g, nxt.p, gn, sc, sc);
+        HIPC(h, hipStreamSynchronize(h->stream));
+        std::swap(cur.p, nxt.p);
+        g = gn;
+    }
+    HIPC(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(d8);
+    *ow = g.w; *oh = g.h;
+    if (out) return dbg_down(h, out, cur.p, g);
+    return TF_OK;
+}
+
+TF_API int tf_dbg_warp(tf_handle* h, const float* I0, const float* I1, const float* u1, const float* u2, int w, int hgt,
+                       float* I1wx, float* I1wy, float* rho_c)
+{
+    if (!h || !I0 || !I1 || !u1 || !u2 || !I1wx || !I1wy || !rho_c || w < 1 || hgt < 1) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    const Geom g = make_geom(w, hgt);
+    // frames: [I0, I1] in one allocation so that pair 0 = (frame 0, frame 1)
+    float* fr = nullptr;
+    HIPC(h, hipMalloc(&fr, 2 * (size_t)g.plane * sizeof(float)));
+    HIPC(h, hipMemset(fr, 0, 2 * (size_t)g.plane * sizeof(float)));
+    DBuf keep; keep.p = fr;
+    HIPC(h, hipMemcpy2D(fr, (size_t)g.pitch * 4, I0, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice));
+    HIPC(h, hipMemcpy2D(fr + g.plane, (size_t)g.pitch * 4, I1, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice));
+    DBuf du1, du2, dwx, dwy, drho;
+    int rc;
+    if ((rc = dbg_up(h, du1, u1, g)) || (rc = dbg_up(h, du2, u2, g)) || (rc = dbg_up(h, dwx, nullptr, g)) ||
+        (rc = dbg_up(h, dwy, nullptr, g)) || (rc = dbg_up(h, drho, nullptr, g))) return rc;
+    PairCtl* ctl = nullptr;
+    HIPC(h, hipMalloc(&ctl, sizeof(PairCtl)));
+    HIPC(h, hipMemset(ctl, 0, sizeof(PairCtl)));
+    WarpArgs wa = {};
+    wa.pyr = fr; wa.off0 = 0; wa.off1 = 1; wa.sb.u1[0] = du1.p; wa.sb.u2[0] = du2.p; wa.ctl = ctl; wa.tab = h->tab;
+    wa.wx = dwx.p; wa.wy = dwy.p; wa.rho = drho.p; wa.g = g;
+    hipLaunchKernelGGL(k_warp, grid64x4(g, 1), dim3(256), 0, h->stream, wa);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(ctl);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_warp: %s", hipGetErrorString(e));
+    if ((rc = dbg_down(h, I1wx, dwx.p, g)) || (rc = dbg_down(h, I1wy, dwy.p, g)) || (rc = dbg_down(h, rho_c, drho.p, g))) return rc;
+    return TF_OK;
+}
+
+TF_API int tf_dbg_median(tf_handle* h, const float* src, int w, int hgt, int ksize, float* dst)
+{
+    if (!h || !src || !dst || w < 1 || hgt < 1 || (ksize != 3 && ksize != 5)) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    const Geom g = make_geom(w, hgt);
+    DBuf a0, a1, b0, b1;
+    int rc;
+    if ((rc = dbg_up(h, a0, src, g)) || (rc = dbg_up(h, a1, nullptr, g)) || (rc = dbg_up(h, b0, src, g)) || (rc = dbg_up(h, b1, nullptr, g))) return rc;
+    PairCtl* ctl = nullptr;
+    HIPC(h, hipMalloc(&ctl, sizeof(PairCtl)));
+    HIPC(h, hipMemset(ctl, 0, sizeof(PairCtl)));
+    MedArgs ma = {};
+    ma.sb.u1[0] = a0.p; ma.sb.u1[1] = a1.p; ma.sb.u2[0] = b0.p; ma.sb.u2[1] = b1.p;
+    ma.ctl = ctl; ma.err = nullptr; ma.errstride = 0; ma.it = 0; ma.thr_q = 0; ma.utog = 0; ma.g = g;
+    const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2);
+    if (ksize == 5) hipLaunchKernelGGL(k_median<5>, gm, dim3(256), 0, h->stream, ma);
+    else hipLaunchKernelGGL(k_median<3>, gm, dim3(256), 0, h->stream, ma);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(ctl);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_median: %s", hipGetErrorString(e));
+    return dbg_down(h, dst, a1.p, g);
+}
+
+TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, const float* rho_c,
+                          float* u1, float* u2, float* p11, float* p12, float* p21, float* p22,
+                          int w, int hgt, int nsteps, int p_is_zero, unsigned long long* err_q)
+{
+    if (!h || !I1wx || !I1wy || !rho_c || !u1 || !u2 || !p11 || !p12 || !p21 || !p22 || w < 1 || hgt < 1 || nsteps < 0)
+        return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    const Geom g = make_geom(w, hgt);
+    DBuf cx, cy, cr, s[12];
+    int rc;
+    if ((rc = dbg_up(h, cx, I1wx, g)) || (rc = dbg_up(h, cy, I1wy, g)) || (rc = dbg_up(h, cr, rho_c, g))) return rc;
+    float* hostp[6] = {u1, u2, p11, p12, p21, p22};
+    for (int k = 0; k < 6; ++k) {
+        if ((rc = dbg_up(h, s[2 * k], hostp[k], g)) || (rc = dbg_up(h, s[2 * k + 1], nullptr, g))) return rc;
+    }
+    PairCtl* ctl = nullptr; u64* errs = nullptr;
+    HIPC(h, hipMalloc(&ctl, sizeof(PairCtl)));
+    HIPC(h, hipMemset(ctl, 0, sizeof(PairCtl)));
+    HIPC(h, hipMalloc(&errs, (size_t)(nsteps + 1) * sizeof(u64)));
+    HIPC(h, hipMemset(errs, 0, (size_t)(nsteps + 1) * sizeof(u64)));
+    IterArgs ia = {};
+    ia.wx = cx.p; ia.wy = cy.p; ia.rho = cr.p;
+    for (int k = 0; k < 2; ++k) {
+        ia.sb.u1[k] = s[0 + k].p; ia.sb.u2[k] = s[2 + k].p; ia.sb.p11[k] = s[4 + k].p;
+        ia.sb.p12[k] = s[6 + k].p; ia.sb.p21[k] = s[8 + k].p; ia.sb.p22[k] = s[10 + k].p;
+    }
+    ia.ctl = ctl; ia.err = errs; ia.errstride = nsteps + 1; ia.thr_q = -1.0; ia.g = g;
+    ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
+    const dim3 gi((g.w + IT_OW - 1) / IT_OW, (g.h + IT_OH - 1) / IT_OH, 1);
+    for (int it = 0; it < nsteps; ++it) {
+        ia.it = it; ia.utog = it; ia.ptog = it; ia.pzero = (p_is_zero && it == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, h->stream, ia);
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && err_q && nsteps > 0) e = hipMemcpy(err_q, errs, (size_t)nsteps * sizeof(u64), hipMemcpyDeviceToHost);
+    (void)hipFree(ctl); (void)hipFree(errs);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_iter: %s", hipGetErrorString(e));
+    const int cur = nsteps & 1;
+    for (int k = 0; k < 6; ++k)
+        if ((rc = dbg_down(h, hostp[k], s[2 * k + cur].p, g))) return rc;
+    return TF_OK;
+}

@@ -1,0 +1,458 @@
+// teeflow_kernels.hip.h -- gfx950 (MI355X) kernels of the DualTVL1 engine.
+//
+// What they compute is OpenCV's CPU DualTVL1 as the reference reaches it through
+// /root/reference/optical_flow/calculate_optical_flow.py:577-578, 642.
+// Arithmetic contract: every float expression is evaluated in the written order with IEEE
+// single/double operations and NO fused multiply-add (build flag -ffp-contract=off), so results
+// are bit-identical to the CPU oracle in oracle/tvl1_oracle.c (which tests/ compare against).
+//
+// Data layout in HBM: every image-like quantity is a stack of fp32 planes [pair|frame][h][pitch],
+// pitch = round_up(w, 32) floats (128-B rows, float4-aligned), plane = pitch*h.  Per level the
+// engine keeps: the frame pyramid (I0/I1 share frames in sequence mode), three per-warp constants
+// (I1wx, I1wy, rho_c -- |grad|^2 is recomputed, I1x/I1y are never materialised) and the
+// ping-pong state u1,u2 (x2) and p11,p12,p21,p22 (x2).
+//
+// All kernels are HBM-bandwidth-bound stencils (no MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define TF_HD __host__ __device__
+#include "median_net.h"
+
+typedef unsigned long long u64;
+
+struct Geom {
+    int w, h, pitch;
+    long long plane;  // floats per pair-plane (pitch*h)
+};
+
+struct PairCtl {
+    int ubase;  // which of the two u buffers holds this pair's current flow at stage start
+    int pbase;  // same for the dual variable
+};
+
+struct StateBufs {
+    float* u1[2]; float* u2[2];
+    float* p11[2]; float* p12[2]; float* p21[2]; float* p22[2];
+};
+
+#define ERR_SCALE_F 1073741824.0f  // 2^30: per-pixel convergence term -> exact integer (oracle D1)
+#define ERR_CAP_F 4096.0f
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+
+// active(pair, it): did iteration it-1 leave error > threshold?  Slots are zeroed per stage, so a pair
+// that stopped earlier reads 0 and stays stopped.
+__device__ __forceinline__ bool pair_active(const u64* errb, int it, double thr_q)
+{
+    if (it == 0) return true;
+    return (double)errb[it - 1] > thr_q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// u8 -> f32 (cv::Mat::convertTo(CV_32F, 1.0)): dense [F][H][W] bytes -> pitched fp32 planes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* __restrict__ src, float* __restrict__ dst, Geom g)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.w) return;
+    dst[(size_t)f * g.plane + (size_t)y * g.pitch + x] = (float)src[((size_t)f * g.h + y) * g.w + x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::resize INTER_LINEAR on CV_32FC1 (see oracle orc_resize_linear for the border rules)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float resize_px(const float* __restrict__ S, int sw, int sh, int spitch,
+                                           int dx, int dy, double scale_x, double scale_y)
+{
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor_f(fx);
+    fx -= (float)sx;
+    bool tail = false;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx + 1 >= sw) { tail = true; if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; } }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor_f(fy);
+    fy -= (float)sy;
+    const float b0 = 1.f - fy, b1 = fy;
+    const int r0 = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
+    const int r1 = sy + 1 >= 0 ? (sy + 1 < sh ? sy + 1 : sh - 1) : 0;
+    const float* S0 = S + (size_t)r0 * spitch;
+    const float* S1 = S + (size_t)r1 * spitch;
+    float t0, t1;
+    if (tail) { t0 = S0[sx]; t1 = S1[sx]; }
+    else {
+        const float a1 = fx, a0 = 1.f - fx;
+        t0 = S0[sx] * a0 + S0[sx + 1] * a1;
+        t1 = S1[sx] * a0 + S1[sx + 1] * a1;
+    }
+    return t0 * b0 + t1 * b1;
+}
+
+// pyramid: one level down for every frame
+__global__ __launch_bounds__(256) void k_pyr_down(const float* __restrict__ src, Geom gs, float* __restrict__ dst, Geom gd,
+                                                  double scale_x, double scale_y)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (dx >= gd.w || dy >= gd.h) return;
+    dst[(size_t)f * gd.plane + (size_t)dy * gd.pitch + dx] =
+        resize_px(src + (size_t)f * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y);
+}
+
+// flow: coarse level -> next finer level, times 1/scaleStep (resize + multiply of DualTVL1::calc)
+__global__ __launch_bounds__(256) void k_flow_up(StateBufs sb, const PairCtl* __restrict__ ctl, Geom gs, Geom gd,
+                                                 double scale_x, double scale_y, float mul)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (dx >= gd.w || dy >= gd.h) return;
+    const int uc = ctl[b].ubase & 1;
+    const size_t di = (size_t)b * gd.plane + (size_t)dy * gd.pitch + dx;
+    sb.u1[uc ^ 1][di] = resize_px(sb.u1[uc] + (size_t)b * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
+    sb.u2[uc ^ 1][di] = resize_px(sb.u2[uc] + (size_t)b * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Warp stage (tvl1flow.cpp: buildFlowMap + 3x cv::remap INTER_CUBIC/BORDER_CONSTANT + calcGradRho).
+// The centred gradient of I1 is evaluated on the fly from a clamped 6x6 patch (bit-identical to
+// gradient-then-remap: each tap's gradient is the same 0.5f*(next-prev) of the same two pixels),
+// so I1x/I1y never exist in HBM.  Output: I1wx, I1wy, rho_c.
+// ---------------------------------------------------------------------------------------------
+struct WarpArgs {
+    const float* pyr;       // this level's frame planes
+    int off0, off1;         // pair b uses frames off0+b (I0) and off1+b (I1)
+    StateBufs sb;
+    const PairCtl* ctl;
+    const float* tab;       // [32][4] bicubic coefficients (A = -0.75)
+    float *wx, *wy, *rho;
+    Geom g;
+};
+
+__global__ __launch_bounds__(256) void k_warp(WarpArgs a)
+{
+    __shared__ float stab[128];
+    if (threadIdx.x < 128) stab[threadIdx.x] = a.tab[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    if (x >= W || y >= H) return;
+    const int uc = a.ctl[b].ubase & 1;
+    const size_t po = (size_t)b * a.g.plane, idx = (size_t)y * pitch + x;
+    const float u1 = a.sb.u1[uc][po + idx], u2 = a.sb.u2[uc][po + idx];
+    const float* __restrict__ I0 = a.pyr + (size_t)(a.off0 + b) * a.g.plane;
+    const float* __restrict__ I1 = a.pyr + (size_t)(a.off1 + b) * a.g.plane;
+    const float mx = (float)x + u1, my = (float)y + u2;
+    const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
+    const float* wxp = stab + (sx & 31) * 4;
+    const float* wyp = stab + (sy & 31) * 4;
+    int ixs = sx >> 5, iys = sy >> 5;
+    ixs = clampi(ixs, -32768, 32767); iys = clampi(iys, -32768, 32767);   // saturate_cast<short>
+    const int ix = ixs - 1, iy = iys - 1;
+    float vI = 0.f, vX = 0.f, vY = 0.f;
+    if (!(ix >= W || ix + 4 <= 0 || iy >= H || iy + 4 <= 0)) {
+        float P[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float* row = I1 + (size_t)clampi(iy - 1 + j, 0, H - 1) * pitch;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) P[j][i] = row[clampi(ix - 1 + i, 0, W - 1)];
+        }
+        float wgt[16];
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) wgt[k1 * 4 + k2] = wyp[k1] * wxp[k2];
+        const unsigned width1 = (unsigned)(W - 3 > 0 ? W - 3 : 0), height1 = (unsigned)(H - 3 > 0 ? H - 3 : 0);
+        if ((unsigned)ix < width1 && (unsigned)iy < height1) {
+            // interior: each source row summed left to right, rows accumulated in order
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) {
+                float rI = P[k1 + 1][1] * wgt[k1 * 4];
+                float rX = (0.5f * (P[k1 + 1][2] - P[k1 + 1][0])) * wgt[k1 * 4];
+                float rY = (0.5f * (P[k1 + 2][1] - P[k1][1])) * wgt[k1 * 4];
+#pragma unroll
+                for (int k2 = 1; k2 < 4; ++k2) {
+                    rI = rI + P[k1 + 1][k2 + 1] * wgt[k1 * 4 + k2];
+                    rX = rX + (0.5f * (P[k1 + 1][k2 + 2] - P[k1 + 1][k2])) * wgt[k1 * 4 + k2];
+                    rY = rY + (0.5f * (P[k1 + 2][k2 + 1] - P[k1][k2 + 1])) * wgt[k1 * 4 + k2];
+                }
+                if (k1 == 0) { vI = rI; vX = rX; vY = rY; }
+                else { vI += rI; vX += rX; vY += rY; }
+            }
+        } else {
+            // partially outside: constant border 0, valid taps accumulated one by one
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) {
+                const int yi = iy + k1;
+                if (yi < 0 || yi >= H) continue;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const int xj = ix + k2;
+                    if (xj < 0 || xj >= W) continue;
+                    vI += P[k1 + 1][k2 + 1] * wgt[k1 * 4 + k2];
+                    vX += (0.5f * (P[k1 + 1][k2 + 2] - P[k1 + 1][k2])) * wgt[k1 * 4 + k2];
+                    vY += (0.5f * (P[k1 + 2][k2 + 1] - P[k1][k2 + 1])) * wgt[k1 * 4 + k2];
+                }
+            }
+        }
+    }
+    a.wx[po + idx] = vX;
+    a.wy[po + idx] = vY;
+    a.rho[po + idx] = ((vI - vX * u1) - vY * u2) - I0[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::medianBlur(u, u, KS) on both flow planes, BORDER_REPLICATE, for pairs still iterating.
+// Tile 64x16 outputs per 256-thread block, staged through LDS with its halo; grid.z = 2*B.
+// ---------------------------------------------------------------------------------------------
+struct MedArgs {
+    StateBufs sb;
+    const PairCtl* ctl;
+    const u64* err; int errstride; int it; double thr_q; int utog;
+    Geom g;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_median(MedArgs a)
+{
+    constexpr int R = KS / 2, TWm = 64, THm = 16, LW = TWm + 2 * R, LH = THm + 2 * R;
+    __shared__ float t[LH][LW];
+    const int b = blockIdx.z >> 1, plane = blockIdx.z & 1;
+    if (!pair_active(a.err + (size_t)b * a.errstride, a.it, a.thr_q)) return;
+    const int uc = (a.ctl[b].ubase ^ a.utog) & 1;
+    const size_t po = (size_t)b * a.g.plane;
+    const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
+    float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
+    const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        t[ly][lx] = src[(size_t)clampi(y0 - R + ly, 0, H - 1) * pitch + clampi(x0 - R + lx, 0, W - 1)];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ly = (threadIdx.x >> 6) + 4 * r, y = y0 + ly;
+        if (x < W && y < H) {
+            float p[KS * KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int i = 0; i < KS; ++i) p[j * KS + i] = t[ly + j][lx + i];
+            dst[(size_t)y * pitch + x] = (KS == 5) ? tf_median25(p) : tf_median9(p);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tvl1_iter: ONE fused inner iteration of procOneScale for a tile:
+//   estimateV (threshold TH) -> divergence(p) -> estimateU (+ convergence term) ->
+//   forwardGradient(u') -> estimateDualVariables
+// 256 threads = 16 quads x 16 rows compute u' on a 64x16 px region (float4 per thread); the block
+// OUTPUTS the 60x15 sub-tile whose forward differences it can form from that region (u' goes
+// through LDS for the x+1 / y+1 neighbours).  u and p are ping-ponged so neighbouring tiles always
+// read the previous iterate.  Algorithmic traffic: 9 plane reads + 6 plane writes = 60 B/px.
+// The convergence sum is accumulated exactly (uint64 of rint(t*2^30)), one atomic per block.
+// ---------------------------------------------------------------------------------------------
+#define IT_TW 64
+#define IT_TH 16
+#define IT_OW 60
+#define IT_OH 15
+
+struct IterArgs {
+    const float *wx, *wy, *rho;
+    StateBufs sb;
+    const PairCtl* ctl;
+    u64* err; int errstride; int it; double thr_q;
+    int utog, ptog, pzero;
+    Geom g;
+    float l_t, theta, taut;
+};
+
+__device__ __forceinline__ float hypot_exact(float a, float b)
+{
+    // oracle D2: (float)sqrt((double)a*a + (double)b*b), all steps correctly rounded
+    return (float)__dsqrt_rn((double)a * (double)a + (double)b * (double)b);
+}
+
+__global__ __launch_bounds__(256) void k_iter(IterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float su1[IT_TH][IT_TW + 4];
+    __shared__ __attribute__((aligned(16))) float su2[IT_TH][IT_TW + 4];
+    __shared__ u64 sred[4];
+    const int b = blockIdx.z;
+    u64* errb = a.err + (size_t)b * a.errstride;
+    if (!pair_active(errb, a.it, a.thr_q)) return;   // block-uniform
+    const PairCtl c = a.ctl[b];
+    const int uc = (c.ubase ^ a.utog) & 1, pc = (c.pbase ^ a.ptog) & 1;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    const int x = blockIdx.x * IT_OW + tx * 4, y = blockIdx.y * IT_OH + ty;
+    const bool inr = x < W && y < H;
+    const size_t po = (size_t)b * a.g.plane;
+    const size_t row = po + (size_t)y * pitch + x;
+
+    float u1n[4], u2n[4], p11c[4], p12c[4], p21c[4], p22c[4];
+    u64 q = 0;
+    const bool outr = inr && tx < 15 && ty < 15;
+    if (inr) {
+        const float4 u1q = ld4(a.sb.u1[uc] + row), u2q = ld4(a.sb.u2[uc] + row);
+        const float4 wxq = ld4(a.wx + row), wyq = ld4(a.wy + row), rq = ld4(a.rho + row);
+        float4 a11 = make_float4(0, 0, 0, 0), a12 = a11, a21 = a11, a22 = a11, up12 = a11, up22 = a11;
+        float l11 = 0.f, l21 = 0.f;
+        if (!a.pzero) {
+            a11 = ld4(a.sb.p11[pc] + row); a12 = ld4(a.sb.p12[pc] + row);
+            a21 = ld4(a.sb.p21[pc] + row); a22 = ld4(a.sb.p22[pc] + row);
+            if (y > 0) { up12 = ld4(a.sb.p12[pc] + row - pitch); up22 = ld4(a.sb.p22[pc] + row - pitch); }
+            if (x > 0) { l11 = a.sb.p11[pc][row - 1]; l21 = a.sb.p21[pc][row - 1]; }
+        }
+        const float u1k[4] = {u1q.x, u1q.y, u1q.z, u1q.w}, u2k[4] = {u2q.x, u2q.y, u2q.z, u2q.w};
+        const float wxv[4] = {wxq.x, wxq.y, wxq.z, wxq.w}, wyv[4] = {wyq.x, wyq.y, wyq.z, wyq.w};
+        const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
+        const float q12u[4] = {up12.x, up12.y, up12.z, up12.w}, q22u[4] = {up22.x, up22.y, up22.z, up22.w};
+        p11c[0] = a11.x; p11c[1] = a11.y; p11c[2] = a11.z; p11c[3] = a11.w;
+        p12c[0] = a12.x; p12c[1] = a12.y; p12c[2] = a12.z; p12c[3] = a12.w;
+        p21c[0] = a21.x; p21c[1] = a21.y; p21c[2] = a21.z; p21c[3] = a21.w;
+        p22c[0] = a22.x; p22c[1] = a22.y; p22c[2] = a22.z; p22c[3] = a22.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xi = x + i;
+            // estimateV
+            const float Ix2 = wxv[i] * wxv[i], Iy2 = wyv[i] * wyv[i];
+            const float grad = Ix2 + Iy2;
+            const float rho = rv[i] + (wxv[i] * u1k[i] + wyv[i] * u2k[i]);
+            const float lg = a.l_t * grad;
+            float d1 = 0.f, d2 = 0.f;
+            if (rho < -lg) { d1 = a.l_t * wxv[i]; d2 = a.l_t * wyv[i]; }
+            else if (rho > lg) { d1 = -a.l_t * wxv[i]; d2 = -a.l_t * wyv[i]; }
+            else if (grad > FLT_EPSILON) { const float fi = -rho / grad; d1 = fi * wxv[i]; d2 = fi * wyv[i]; }
+            const float v1 = u1k[i] + d1, v2 = u2k[i] + d2;
+            // divergence (backward differences; upstream's first-row / first-column forms)
+            const float p11l = i == 0 ? l11 : p11c[i - 1];
+            const float p21l = i == 0 ? l21 : p21c[i - 1];
+            float div1, div2;
+            if (y > 0 && xi > 0) {
+                div1 = (p11c[i] - p11l) + (p12c[i] - q12u[i]);
+                div2 = (p21c[i] - p21l) + (p22c[i] - q22u[i]);
+            } else if (y == 0 && xi > 0) {
+                div1 = (p11c[i] - p11l) + p12c[i];
+                div2 = (p21c[i] - p21l) + p22c[i];
+            } else if (xi == 0 && y > 0) {
+                div1 = (p11c[i] + p12c[i]) - q12u[i];
+                div2 = (p21c[i] + p22c[i]) - q22u[i];
+            } else {
+                div1 = p11c[i] + p12c[i];
+                div2 = p21c[i] + p22c[i];
+            }
+            // estimateU
+            u1n[i] = v1 + a.theta * div1;
+            u2n[i] = v2 + a.theta * div2;
+            if (outr && xi < W) {
+                const float e1 = u1n[i] - u1k[i], e2 = u2n[i] - u2k[i];
+                const float t = e1 * e1 + e2 * e2;
+                q += (u64)__float2ll_rn(fminf(t, ERR_CAP_F) * ERR_SCALE_F);
+            }
+        }
+        st4(&su1[ty][tx * 4], make_float4(u1n[0], u1n[1], u1n[2], u1n[3]));
+        st4(&su2[ty][tx * 4], make_float4(u2n[0], u2n[1], u2n[2], u2n[3]));
+    }
+    __syncthreads();
+    if (outr) {
+        float o11[4], o12[4], o21[4], o22[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xi = x + i;
+            // forwardGradient of u' (0 in the last column / row)
+            const float r1 = i < 3 ? u1n[i + 1] : su1[ty][tx * 4 + 4];
+            const float r2 = i < 3 ? u2n[i + 1] : su2[ty][tx * 4 + 4];
+            const float u1x = xi < W - 1 ? r1 - u1n[i] : 0.f;
+            const float u2x = xi < W - 1 ? r2 - u2n[i] : 0.f;
+            const float u1y = y < H - 1 ? su1[ty + 1][tx * 4 + i] - u1n[i] : 0.f;
+            const float u2y = y < H - 1 ? su2[ty + 1][tx * 4 + i] - u2n[i] : 0.f;
+            // estimateDualVariables
+            const float ng1 = 1.0f + a.taut * hypot_exact(u1x, u1y);
+            const float ng2 = 1.0f + a.taut * hypot_exact(u2x, u2y);
+            o11[i] = (p11c[i] + a.taut * u1x) / ng1;
+            o12[i] = (p12c[i] + a.taut * u1y) / ng1;
+            o21[i] = (p21c[i] + a.taut * u2x) / ng2;
+            o22[i] = (p22c[i] + a.taut * u2y) / ng2;
+        }
+        st4(a.sb.u1[uc ^ 1] + row, make_float4(u1n[0], u1n[1], u1n[2], u1n[3]));
+        st4(a.sb.u2[uc ^ 1] + row, make_float4(u2n[0], u2n[1], u2n[2], u2n[3]));
+        st4(a.sb.p11[pc ^ 1] + row, make_float4(o11[0], o11[1], o11[2], o11[3]));
+        st4(a.sb.p12[pc ^ 1] + row, make_float4(o12[0], o12[1], o12[2], o12[3]));
+        st4(a.sb.p21[pc ^ 1] + row, make_float4(o21[0], o21[1], o21[2], o21[3]));
+        st4(a.sb.p22[pc ^ 1] + row, make_float4(o22[0], o22[1], o22[2], o22[3]));
+    }
+    // exact convergence sum: wave shuffle reduction -> 4 partials in LDS -> one atomic per block
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 tot = sred[0] + sred[1] + sred[2] + sred[3];
+        atomicAdd(&errb[a.it], tot);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// control kernels (a few threads; they keep the stop/continue decisions on the device)
+// ---------------------------------------------------------------------------------------------
+// number of pairs still iterating after `it_done` iterations -> *out
+__global__ void k_probe(const u64* __restrict__ err, int errstride, int B, int it_done, double thr_q, int* out)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x)
+        c += pair_active(err + (size_t)b * errstride, it_done, thr_q) ? 1 : 0;
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = cnt;
+}
+
+// end of one (level, warp) stage: executed iteration counts -> stats; advance the ping-pong bases
+__global__ void k_stage_end(const u64* __restrict__ err, int errstride, PairCtl* ctl, int* iters, int B,
+                            int total, int inner, int median_on, double thr_q, int level, int warp, int nlev, int warps)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const u64* e = err + (size_t)b * errstride;
+    int n_it = total;
+    for (int j = 0; j < total; ++j)
+        if (!((double)e[j] > thr_q)) { n_it = j + 1; break; }
+    const int n_out = n_it > 0 ? (n_it - 1) / inner + 1 : 0;
+    PairCtl c = ctl[b];
+    c.ubase = (c.ubase + n_it + (median_on ? n_out : 0)) & 1;
+    c.pbase = (c.pbase + n_it) & 1;
+    ctl[b] = c;
+    int* o = iters + (((size_t)b * nlev + level) * warps + warp) * 2;
+    o[0] = n_it; o[1] = n_out;
+}
+
+// mode 0: reset (coarsest level start); mode 1: after k_flow_up (flow moved to the other buffer, p restarts)
+__global__ void k_ctl_set(PairCtl* ctl, int B, int mode)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (mode == 0) { ctl[b].ubase = 0; ctl[b].pbase = 0; }
+    else { ctl[b].ubase ^= 1; ctl[b].pbase = 0; }
+}
+
+// merge(u1,u2) -> interleaved [B][H][W][2], times the caller's unit scale (reference :600)
+__global__ __launch_bounds__(256) void k_output(StateBufs sb, const PairCtl* __restrict__ ctl, Geom g, float scale,
+                                                float* __restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const int uc = ctl[b].ubase & 1;
+    const size_t i = (size_t)b * g.plane + (size_t)y * g.pitch + x;
+    float2 v = make_float2(sb.u1[uc][i] * scale, sb.u2[uc][i] * scale);
+    reinterpret_cast<float2*>(out)[((size_t)b * g.h + y) * g.w + x] = v;
+}

@@ -1,0 +1,167 @@
+"""`DenseFlow`: the object that takes the place of cv2's DenseOpticalFlow on the reference's hot path.
+
+Reference call sites it is a drop-in for (/root/reference/optical_flow/calculate_optical_flow.py):
+  :577  OF_model = cv2.optflow.createOptFlow_DualTVL1()        -> createOptFlow_DualTVL1()
+  :575  OF_model = cv2.cuda.OpticalFlowDual_TVL1.create()      -> createOptFlow_DualTVL1()
+  :578  OF_model.setLambda(config.lambda_value)                -> DenseFlow.setLambda
+  :631/:638/:642  flow = OF_model.calc(I0, I1, None)           -> DenseFlow.calc
+
+Same protocol: `calc(I0: uint8[H,W], I1: uint8[H,W], None) -> float32[H,W,2]`, the 12 cv2 getters/setters,
+not re-entrant, result owned by the caller.  Everything is computed by hand-written HIP kernels through the
+C ABI in include/teeflow.h; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .exceptions import OpticalFlowCalculationError
+
+
+def _u8_image_stack(a, name, ndim):
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise OpticalFlowCalculationError(f"{name} must be uint8 (CV_8UC1), got {a.dtype}")
+    if a.ndim != ndim:
+        raise OpticalFlowCalculationError(f"{name} must have {ndim} dimensions, got shape {a.shape}")
+    return np.ascontiguousarray(a)
+
+
+class DenseFlow:
+    """MI355X DualTVL1 solver with the cv2.DenseOpticalFlow calling convention."""
+
+    _SETTERS = {"Tau": "tau", "Lambda": "lambda", "Theta": "theta", "ScalesNumber": "nscales",
+                "WarpingsNumber": "warps", "Epsilon": "epsilon", "InnerIterations": "inner_iterations",
+                "OuterIterations": "outer_iterations", "ScaleStep": "scale_step", "Gamma": "gamma",
+                "MedianFiltering": "median_filtering", "UseInitialFlow": "use_initial_flow"}
+
+    def __init__(self, device_id=0, max_batch=128, **params):
+        self._L = _lib.load()
+        p = _lib.TfParams()
+        _lib.check(self._L.tf_default_params(C.byref(p)), None, "tf_default_params")
+        p.max_batch = int(max_batch)
+        for k, v in params.items():
+            key = "lambda_" if k in ("lambda", "lambda_") else k
+            if not hasattr(p, key):
+                raise OpticalFlowCalculationError(f"unknown DualTVL1 parameter {k!r}")
+            setattr(p, key, v)
+        h = C.c_void_p()
+        _lib.check(self._L.tf_create(C.byref(p), int(device_id), C.byref(h)), None, "tf_create")
+        self._h = h
+        self.device_id = int(device_id)
+        self.last_stats = None
+
+    # ---- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the 12 cv2 setters/getters (setLambda is the one the reference calls, :578) -------------
+    def _set(self, key, value):
+        _lib.check(self._L.tf_set_param(self._h, _lib.PARAM_KEYS[key], float(value)), self._h, f"set {key}")
+
+    def _get(self, key):
+        v = C.c_double()
+        _lib.check(self._L.tf_get_param(self._h, _lib.PARAM_KEYS[key], C.byref(v)), self._h, f"get {key}")
+        return v.value
+
+    def __getattr__(self, name):
+        if name.startswith(("set", "get")) and name[3:] in DenseFlow._SETTERS:
+            key = DenseFlow._SETTERS[name[3:]]
+            is_int = key in ("nscales", "warps", "inner_iterations", "outer_iterations", "median_filtering")
+            if name.startswith("set"):
+                return lambda v: self._set(key, v)
+            if key == "use_initial_flow":
+                return lambda: bool(self._get(key))
+            return (lambda: int(self._get(key))) if is_int else (lambda: self._get(key))
+        raise AttributeError(name)
+
+    # ---- engine controls -----------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr):
+        """Run on a caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
+        _lib.check(self._L.tf_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)), self._h, "tf_set_stream")
+
+    def set_profile(self, level):
+        _lib.check(self._L.tf_set_profile(self._h, int(level)), self._h, "tf_set_profile")
+
+    def _finish(self, st):
+        self.last_stats = st.as_dict()
+
+    def last_iters(self):
+        """Executed (inner, outer) iteration counts of the last call: int32 [pairs, levels, warps, 2]."""
+        s = self.last_stats
+        n = s["n_pairs"] * s["nscales_used"] * s["warps"] * 2
+        out = np.zeros(n, np.int32)
+        w = C.c_size_t()
+        _lib.check(self._L.tf_get_iters(self._h, out.ctypes.data_as(C.c_void_p), n, C.byref(w)), self._h, "tf_get_iters")
+        return out.reshape(s["n_pairs"], s["nscales_used"], s["warps"], 2)
+
+    # ---- cv2 protocol --------------------------------------------------------------------------
+    def calc(self, I0, I1, flow=None):
+        """flow = OF_model.calc(I0, I1, None): uint8 [H,W] x2 -> float32 [H,W,2] (x, y displacement)."""
+        I0 = _u8_image_stack(I0, "I0", 2)
+        I1 = _u8_image_stack(I1, "I1", 2)
+        if I0.shape != I1.shape:
+            raise OpticalFlowCalculationError(f"I0 and I1 sizes differ: {I0.shape} vs {I1.shape}")
+        H, W = I0.shape
+        out = np.empty((H, W, 2), np.float32)
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_pair(self._h, I0.ctypes.data, I1.ctypes.data, H, W, out.ctypes.data, C.byref(st)),
+                   self._h, "tf_calc_pair")
+        self._finish(st)
+        return out
+
+    # ---- batched forms (the data-parallel path the reference lacks) ------------------------------
+    def calc_batch(self, frames, scale=1.0):
+        """frames uint8 [N,H,W] -> float32 [N-1,H,W,2]: flow(frame i -> i+1) * scale (reference loop :584-597)."""
+        frames = _u8_image_stack(frames, "frames", 3)
+        N, H, W = frames.shape
+        if N < 2:
+            raise OpticalFlowCalculationError("need at least 2 frames")
+        out = np.empty((N - 1, H, W, 2), np.float32)
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_seq(self._h, frames.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(st)),
+                   self._h, "tf_calc_seq")
+        self._finish(st)
+        return out
+
+    def calc_pairs(self, I0s, I1s):
+        """B independent pairs: uint8 [B,H,W] x2 -> float32 [B,H,W,2]."""
+        I0s = _u8_image_stack(I0s, "I0s", 3)
+        I1s = _u8_image_stack(I1s, "I1s", 3)
+        if I0s.shape != I1s.shape:
+            raise OpticalFlowCalculationError(f"I0s and I1s sizes differ: {I0s.shape} vs {I1s.shape}")
+        B, H, W = I0s.shape
+        out = np.empty((B, H, W, 2), np.float32)
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_pairs(self._h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, out.ctypes.data, C.byref(st)),
+                   self._h, "tf_calc_pairs")
+        self._finish(st)
+        return out
+
+    def calc_pairs_device(self, dI0s_ptr, dI1s_ptr, B, H, W, dflow_ptr, scale=1.0):
+        """Device-resident form: raw device pointers (e.g. tensor.data_ptr()); result written to dflow_ptr."""
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_pairs_device(self._h, C.c_void_p(dI0s_ptr), C.c_void_p(dI1s_ptr), int(B), int(H), int(W),
+                                                float(scale), C.c_void_p(dflow_ptr), C.byref(st)), self._h, "tf_calc_pairs_device")
+        self._finish(st)
+        return self.last_stats
+
+    def calc_seq_device(self, dframes_ptr, N, H, W, dflow_ptr, scale=1.0):
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_seq_device(self._h, C.c_void_p(dframes_ptr), int(N), int(H), int(W), float(scale),
+                                              C.c_void_p(dflow_ptr), C.byref(st)), self._h, "tf_calc_seq_device")
+        self._finish(st)
+        return self.last_stats
+
+
+def createOptFlow_DualTVL1(device_id=0, **kw):
+    """Name-compatible factory for cv2.optflow.createOptFlow_DualTVL1() (reference :577)."""
+    return DenseFlow(device_id=device_id, **kw)

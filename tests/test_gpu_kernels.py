@@ -1,0 +1,119 @@
+"""Kernel-level parity on the GPU: each HIP kernel, called through the C ABI's tf_dbg_* hooks, against the
+oracle's restatement of the same OpenCV step.  Bar: BIT-EXACT (the kernels and the oracle evaluate the same
+IEEE operations in the same order, no FMA)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _rng_img(seed, h, w, lo=0.0, hi=255.0):
+    return np.random.default_rng(seed).uniform(lo, hi, (h, w)).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (210, 210), (17, 16), (512, 512)])
+def test_pyramid_levels_bit_exact(engine, oracle, shape):
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    img = np.random.default_rng(1).integers(0, 256, (h, w), dtype=np.uint8)
+    for level in (0, 1, 2):
+        ref = oracle.pyramid_level(img, level)
+        ow, oh = C.c_int(), C.c_int()
+        _lib.check(L.tf_dbg_pyramid(engine._h, _ptr(img), h, w, level, None, C.byref(ow), C.byref(oh)), engine._h)
+        assert (oh.value, ow.value) == ref.shape
+        out = np.empty(ref.shape, np.float32)
+        _lib.check(L.tf_dbg_pyramid(engine._h, _ptr(img), h, w, level, _ptr(out), C.byref(ow), C.byref(oh)), engine._h)
+        assert np.array_equal(out, ref), f"level {level}: max diff {np.abs(out - ref).max()}"
+
+
+@pytest.mark.parametrize("src_shape,dst_shape", [((210, 210), (262, 262)), ((33, 47), (41, 59)), ((16, 16), (20, 20)),
+                                                 ((328, 328), (410, 410))])
+def test_flow_upsample_resize_bit_exact(engine, oracle, src_shape, dst_shape):
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    sh, sw = src_shape
+    dh, dw = dst_shape
+    src = _rng_img(2, sh, sw, -5, 5)
+    ref = oracle.resize_linear(src, dw, dh) * np.float32(1.25)
+    out = np.empty((dh, dw), np.float32)
+    _lib.check(L.tf_dbg_resize(engine._h, _ptr(src), sw, sh, _ptr(out), dw, dh, dw / sw, dh / sh, 1.25), engine._h)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("shape,amp", [((64, 64), 3.0), ((97, 131), 8.0), ((210, 210), 1.0), ((40, 300), 60.0),
+                                       ((20, 18), 30.0)])
+def test_warp_bit_exact(engine, oracle, shape, amp):
+    """buildFlowMap + 3x remap(INTER_CUBIC, BORDER_CONSTANT) + calcGradRho; `amp` pushes samples across and
+    beyond the borders (partial-tap and fully-outside cases)."""
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(3)
+    I0, I1 = _rng_img(4, h, w), _rng_img(5, h, w)
+    u1 = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
+    u2 = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
+    u1[0, 0] = 1e6   # far outside (saturate_cast<short> path)
+    u2[-1, -1] = -1e6
+    r_wx, r_wy, r_grad, r_rho = oracle.warp(I0, I1, u1, u2)
+    wx, wy, rho = (np.empty((h, w), np.float32) for _ in range(3))
+    _lib.check(L.tf_dbg_warp(engine._h, _ptr(I0), _ptr(I1), _ptr(u1), _ptr(u2), w, h, _ptr(wx), _ptr(wy), _ptr(rho)), engine._h)
+    assert np.array_equal(wx, r_wx)
+    assert np.array_equal(wy, r_wy)
+    assert np.array_equal(rho, r_rho)
+    assert np.array_equal(wx * wx + wy * wy, r_grad)   # |grad|^2 is recomputed in tvl1_iter, never stored
+
+
+@pytest.mark.parametrize("ksize", [3, 5])
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (5, 7), (1, 40), (210, 210)])
+def test_median_bit_exact(engine, oracle, shape, ksize):
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    src = _rng_img(6, h, w, -3, 3)
+    src[::7, ::5] = 0.0  # ties
+    ref = oracle.median_blur(src, ksize)
+    out = np.empty((h, w), np.float32)
+    _lib.check(L.tf_dbg_median(engine._h, _ptr(src), w, h, ksize, _ptr(out)), engine._h)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (210, 210), (15, 60), (16, 61), (31, 121), (512, 512)])
+@pytest.mark.parametrize("pzero", [0, 1])
+def test_iterate_bit_exact(engine, oracle, shape, pzero):
+    """k steps of the fused tvl1_iter kernel == k oracle iterations (state AND exact error sums)."""
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(7)
+    I0, I1 = _rng_img(8, h, w), _rng_img(9, h, w)
+    # smooth-ish images make all three threshold branches occur
+    from scipy import ndimage
+    I0 = ndimage.gaussian_filter(I0, 1.5).astype(np.float32)
+    I1 = ndimage.gaussian_filter(I1, 1.5).astype(np.float32)
+    u1 = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    u2 = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    wx, wy, grad, rho = oracle.warp(I0, I1, u1, u2)
+    wx[3:6, 3:9] = 0.0  # grad <= FLT_EPSILON branch
+    wy[3:6, 3:9] = 0.0
+    grad = wx * wx + wy * wy
+    if pzero:
+        p = [np.zeros((h, w), np.float32) for _ in range(4)]
+    else:
+        p = [rng.uniform(-0.5, 0.5, (h, w)).astype(np.float32) for _ in range(4)]
+    nsteps = 5
+    ref = oracle.iterate(wx, wy, grad, rho, u1, u2, *p, nsteps)
+    st = [a.copy() for a in (u1, u2, *p)]
+    err = np.zeros(nsteps, np.uint64)
+    _lib.check(L.tf_dbg_iterate(engine._h, _ptr(wx), _ptr(wy), _ptr(rho), *[_ptr(a) for a in st], w, h, nsteps, pzero,
+                                _ptr(err)), engine._h)
+    names = ["u1", "u2", "p11", "p12", "p21", "p22"]
+    for n, a, r in zip(names, st, ref[:6]):
+        assert np.array_equal(a, r), f"{n}: {np.sum(a != r)} px differ, max {np.abs(a - r).max()}"
+    assert np.array_equal(err, ref[6])

@@ -1,0 +1,122 @@
+"""End-to-end parity of the HIP DualTVL1 path (through the C ABI) against the CPU oracle.
+
+north_star's tolerance is <= 1e-3 mean EPE; because kernels and oracle share one arithmetic contract the
+tests demand more: identical executed-iteration counts and BIT-EXACT flow.  (Parity against real OpenCV is
+unpinned -- cv2 is not installable here; see oracle/tvl1_oracle.c.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPE_TOL_MEAN = 1e-3   # BASELINE.json north_star
+EPE_TOL_MAX = 1e-2
+
+
+def _epe(a, b):
+    return np.sqrt(((a - b) ** 2).sum(-1))
+
+
+@pytest.mark.parametrize("seed,H,W", [(0, 128, 128), (1, 160, 200), (2, 256, 256), (3, 97, 131), (5, 40, 64)])
+def test_pair_matches_oracle(engine, oracle, seed, H, W):
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, _ = speckle_pair(seed, H, W)
+    ref, ref_it, ref_levels = oracle.tvl1_calc(I0, I1, return_iters=True)
+    out = engine.calc(I0, I1, None)
+    it = engine.last_iters()[0]
+    assert out.dtype == np.float32 and out.shape == (H, W, 2)
+    assert engine.last_stats["nscales_used"] == ref_levels
+    assert np.array_equal(it, ref_it[:ref_levels]), f"iteration counts differ:\n{it[..., 0]}\n{ref_it[:ref_levels, :, 0]}"
+    e = _epe(out, ref)
+    assert e.mean() <= EPE_TOL_MEAN and e.max() <= EPE_TOL_MAX
+    assert np.array_equal(out, ref), f"not bit-exact: {np.sum(out != ref)} values differ, max {np.abs(out - ref).max()}"
+
+
+def test_full_size_512_matches_oracle(engine, oracle):
+    """BASELINE.json configs[1]: one 512x512 pair, all-default DualTVL1 (lambda 0.15)."""
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, truth = speckle_pair(0, 512, 512)
+    ref, ref_it, _ = oracle.tvl1_calc(I0, I1, return_iters=True)
+    out = engine.calc(I0, I1, None)
+    assert np.array_equal(engine.last_iters()[0], ref_it)
+    e = _epe(out, ref)
+    assert e.mean() <= EPE_TOL_MEAN and e.max() <= EPE_TOL_MAX
+    assert np.array_equal(out, ref)
+    # and the solver actually solves the problem (interior EPE vs the known synthetic flow)
+    assert _epe(out, truth)[16:-16, 16:-16].mean() < 0.1
+
+
+def test_identical_frames_give_exact_zero(engine):
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, _, _ = speckle_pair(11, 96, 96)
+    out = engine.calc(I0, I0, None)
+    assert np.all(out == 0.0)
+
+
+def test_batch_equals_singles_and_sequence_mode(engine, oracle):
+    """tf_calc_pairs / tf_calc_seq: lock-step batching must not change any pair's result."""
+    from tee_optical_flow_amd.synth import speckle_pairs, speckle_sequence
+    I0s, I1s = speckle_pairs(range(20, 27), 96, 120)
+    flows = engine.calc_pairs(I0s, I1s)
+    iters = engine.last_iters()
+    for b in range(len(I0s)):
+        ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], return_iters=True)
+        assert np.array_equal(flows[b], ref), f"pair {b}"
+        assert np.array_equal(iters[b], ref_it[:nl])
+    frames = speckle_sequence(30, 6, 80, 96)
+    fseq = engine.calc_batch(frames, scale=2.5)
+    assert fseq.shape == (5, 80, 96, 2)
+    for i in range(5):
+        ref = oracle.tvl1_calc(frames[i], frames[i + 1])
+        assert np.array_equal(fseq[i], ref * np.float32(2.5)), f"seq pair {i}"
+
+
+def test_sub_batching_when_batch_exceeds_capacity(oracle):
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs
+    eng = T.DenseFlow(max_batch=3)
+    I0s, I1s = speckle_pairs(range(40, 47), 64, 64)
+    flows = eng.calc_pairs(I0s, I1s)
+    for b in range(7):
+        assert np.array_equal(flows[b], oracle.tvl1_calc(I0s[b], I1s[b]))
+    eng.close()
+
+
+@pytest.mark.parametrize("params", [dict(lambda_=0.05), dict(median_filtering=3), dict(median_filtering=1),
+                                    dict(nscales=3, warps=2), dict(inner_iterations=7, outer_iterations=3),
+                                    dict(epsilon=0.05, tau=0.2, theta=0.25), dict(scale_step=0.5)])
+def test_non_default_parameters_match_oracle(oracle, params):
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, _ = speckle_pair(50, 120, 136)
+    eng = T.DenseFlow(**params)
+    out = eng.calc(I0, I1, None)
+    it = eng.last_iters()[0]
+    op = oracle.default_params(**{("lambda" if k == "lambda_" else k): v for k, v in params.items()})
+    ref, ref_it, nl = oracle.tvl1_calc(I0, I1, op, return_iters=True)
+    assert np.array_equal(it, ref_it[:nl])
+    assert np.array_equal(out, ref)
+    eng.close()
+
+
+def test_symmetries(engine):
+    """SURVEY.md 8c item 3 (behavioural KATs on the GPU path itself): transpose swaps (u,v)."""
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, _ = speckle_pair(60, 128, 128)
+    f = engine.calc(I0, I1, None)
+    ft = engine.calc(np.ascontiguousarray(I0.T), np.ascontiguousarray(I1.T), None)
+    d = _epe(ft.transpose(1, 0, 2)[..., ::-1], f)
+    assert d.mean() < 5e-2
+
+
+def test_error_behaviour(engine):
+    from tee_optical_flow_amd import OpticalFlowCalculationError
+    a = np.zeros((32, 32), np.uint8)
+    with pytest.raises(OpticalFlowCalculationError):
+        engine.calc(a, np.zeros((32, 33), np.uint8), None)
+    with pytest.raises(OpticalFlowCalculationError):
+        engine.calc(a.astype(np.float32), a.astype(np.float32), None)
+    with pytest.raises(OpticalFlowCalculationError):
+        engine.setGamma(0.5)          # unsupported -> loud error, parameter unchanged
+    assert engine.getGamma() == 0.0
+    engine.setLambda(0.15)
+    assert engine.getLambda() == 0.15
