@@ -36,11 +36,34 @@ def build(force=False):
 _lib = None
 
 
+def effective_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup quota). A GPU box exposes every hardware
+    thread of the host but grants a small CPU share; an OpenMP team sized by nproc would spin on it."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # never spin on an oversubscribed box
         L = C.CDLL(_LIB_PATH)
         fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
@@ -61,6 +84,7 @@ def lib():
         L.orc_tvl1_calc.restype = C.c_int
         L.orc_pyramid_level.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_set_num_threads(min(effective_cpus(), 16))
         _lib = L
     return _lib
 

@@ -92,7 +92,7 @@ inline int cv_round_d(double v) { return (int)lrint(v); }   // saturate_cast<int
 
 Geom make_geom(int w, int h)
 {
-    Geom g; g.w = w; g.h = h; g.pitch = round_up(w, 32); g.plane = (long long)g.pitch * h;
+    Geom g; g.w = w; g.h = h; g.pitch = round_up(w, 32); g.plane = (long long)g.pitch * h; g.splane = g.plane;
     return g;
 }
 
@@ -136,6 +136,7 @@ int compute_levels(const tf_params& P, int H, int W, Geom* lv)
         const int w = cv_round_d(lv[s - 1].w * P.scale_step), hh = cv_round_d(lv[s - 1].h * P.scale_step);
         if (w < 16 || hh < 16) break;
         lv[s] = make_geom(w, hh);
+        lv[s].splane = lv[0].plane;
         n = s + 1;
     }
     return n;
@@ -287,8 +288,8 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
     }
     const int L = h->nlev - 1;
     hipLaunchKernelGGL(k_ctl_set, dim3((B + 255) / 256), dim3(256), 0, s, h->ctl, B, 0);
-    HIPC(h, hipMemsetAsync(h->sb.u1[0], 0, (size_t)B * h->lv[L].plane * sizeof(float), s));
-    HIPC(h, hipMemsetAsync(h->sb.u2[0], 0, (size_t)B * h->lv[L].plane * sizeof(float), s));
+    HIPC(h, hipMemset2DAsync(h->sb.u1[0], (size_t)h->lv[L].splane * sizeof(float), 0, (size_t)h->lv[L].plane * sizeof(float), B, s));
+    HIPC(h, hipMemset2DAsync(h->sb.u2[0], (size_t)h->lv[L].splane * sizeof(float), 0, (size_t)h->lv[L].plane * sizeof(float), B, s));
     for (int l = L; l >= 0; --l) {
         for (int wi = 0; wi < P.warps; ++wi) {
             int rc = run_stage(h, l, wi, B, off0, off1);
@@ -424,13 +425,15 @@ struct DBuf {
 int dbg_up(tf_handle* h, DBuf& d, const float* src, const Geom& g)
 {
     HIPC(h, hipMalloc(&d.p, (size_t)g.plane * sizeof(float)));
-    HIPC(h, hipMemset(d.p, 0, (size_t)g.plane * sizeof(float)));
-    if (src) HIPC(h, hipMemcpy2D(d.p, (size_t)g.pitch * 4, src, (size_t)g.w * 4, (size_t)g.w * 4, g.h, hipMemcpyHostToDevice));
+    // stream-ordered on the handle's (non-blocking) stream: legacy-stream copies would race with its kernels
+    HIPC(h, hipMemsetAsync(d.p, 0, (size_t)g.plane * sizeof(float), h->stream));
+    if (src) HIPC(h, hipMemcpy2DAsync(d.p, (size_t)g.pitch * 4, src, (size_t)g.w * 4, (size_t)g.w * 4, g.h, hipMemcpyHostToDevice, h->stream));
     return TF_OK;
 }
 int dbg_down(tf_handle* h, float* dst, const float* d, const Geom& g)
 {
-    HIPC(h, hipMemcpy2D(dst, (size_t)g.w * 4, d, (size_t)g.pitch * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
+    HIPC(h, hipMemcpy2DAsync(dst, (size_t)g.w * 4, d, (size_t)g.pitch * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
     return TF_OK;
 }
 
@@ -499,7 +502,8 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
         }
     }
     if ((e = hipMalloc(&h->tab, sizeof tab)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemcpy(h->tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    if ((e = hipMemcpyAsync(h->tab, tab, sizeof tab, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return bail(e, "hipMemcpy");
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = h;
     return TF_OK;
 }
@@ -643,7 +647,7 @@ TF_API int tf_dbg_pyramid(tf_handle* h, const uint8_t* img, int H, int W, int le
     Geom g = make_geom(W, H);
     uint8_t* d8 = nullptr;
     HIPC(h, hipMalloc(&d8, (size_t)H * W));
-    HIPC(h, hipMemcpy(d8, img, (size_t)H * W, hipMemcpyHostToDevice));
+    HIPC(h, hipMemcpyAsync(d8, img, (size_t)H * W, hipMemcpyHostToDevice, h->stream));
     DBuf cur;
     int rc = dbg_up(h, cur, nullptr, g);
     if (rc) { (void)hipFree(d8); return rc; }
@@ -675,17 +679,17 @@ TF_API int tf_dbg_warp(tf_handle* h, const float* I0, const float* I1, const flo
     // frames: [I0, I1] in one allocation so that pair 0 = (frame 0, frame 1)
     float* fr = nullptr;
     HIPC(h, hipMalloc(&fr, 2 * (size_t)g.plane * sizeof(float)));
-    HIPC(h, hipMemset(fr, 0, 2 * (size_t)g.plane * sizeof(float)));
     DBuf keep; keep.p = fr;
-    HIPC(h, hipMemcpy2D(fr, (size_t)g.pitch * 4, I0, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice));
-    HIPC(h, hipMemcpy2D(fr + g.plane, (size_t)g.pitch * 4, I1, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice));
+    HIPC(h, hipMemsetAsync(fr, 0, 2 * (size_t)g.plane * sizeof(float), h->stream));
+    HIPC(h, hipMemcpy2DAsync(fr, (size_t)g.pitch * 4, I0, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipMemcpy2DAsync(fr + g.plane, (size_t)g.pitch * 4, I1, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream));
     DBuf du1, du2, dwx, dwy, drho;
     int rc;
     if ((rc = dbg_up(h, du1, u1, g)) || (rc = dbg_up(h, du2, u2, g)) || (rc = dbg_up(h, dwx, nullptr, g)) ||
         (rc = dbg_up(h, dwy, nullptr, g)) || (rc = dbg_up(h, drho, nullptr, g))) return rc;
     PairCtl* ctl = nullptr;
     HIPC(h, hipMalloc(&ctl, sizeof(PairCtl)));
-    HIPC(h, hipMemset(ctl, 0, sizeof(PairCtl)));
+    HIPC(h, hipMemsetAsync(ctl, 0, sizeof(PairCtl), h->stream));
     WarpArgs wa = {};
     wa.pyr = fr; wa.off0 = 0; wa.off1 = 1; wa.sb.u1[0] = du1.p; wa.sb.u2[0] = du2.p; wa.ctl = ctl; wa.tab = h->tab;
     wa.wx = dwx.p; wa.wy = dwy.p; wa.rho = drho.p; wa.g = g;
@@ -707,7 +711,7 @@ TF_API int tf_dbg_median(tf_handle* h, const float* src, int w, int hgt, int ksi
     if ((rc = dbg_up(h, a0, src, g)) || (rc = dbg_up(h, a1, nullptr, g)) || (rc = dbg_up(h, b0, src, g)) || (rc = dbg_up(h, b1, nullptr, g))) return rc;
     PairCtl* ctl = nullptr;
     HIPC(h, hipMalloc(&ctl, sizeof(PairCtl)));
-    HIPC(h, hipMemset(ctl, 0, sizeof(PairCtl)));
+    HIPC(h, hipMemsetAsync(ctl, 0, sizeof(PairCtl), h->stream));
     MedArgs ma = {};
     ma.sb.u1[0] = a0.p; ma.sb.u1[1] = a1.p; ma.sb.u2[0] = b0.p; ma.sb.u2[1] = b1.p;
     ma.ctl = ctl; ma.err = nullptr; ma.errstride = 0; ma.it = 0; ma.thr_q = 0; ma.utog = 0; ma.g = g;
@@ -737,9 +741,9 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     }
     PairCtl* ctl = nullptr; u64* errs = nullptr;
     HIPC(h, hipMalloc(&ctl, sizeof(PairCtl)));
-    HIPC(h, hipMemset(ctl, 0, sizeof(PairCtl)));
+    HIPC(h, hipMemsetAsync(ctl, 0, sizeof(PairCtl), h->stream));
     HIPC(h, hipMalloc(&errs, (size_t)(nsteps + 1) * sizeof(u64)));
-    HIPC(h, hipMemset(errs, 0, (size_t)(nsteps + 1) * sizeof(u64)));
+    HIPC(h, hipMemsetAsync(errs, 0, (size_t)(nsteps + 1) * sizeof(u64), h->stream));
     IterArgs ia = {};
     ia.wx = cx.p; ia.wy = cy.p; ia.rho = cr.p;
     for (int k = 0; k < 2; ++k) {
@@ -754,7 +758,10 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
         hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, h->stream, ia);
     }
     hipError_t e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess && err_q && nsteps > 0) e = hipMemcpy(err_q, errs, (size_t)nsteps * sizeof(u64), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && err_q && nsteps > 0) {
+        e = hipMemcpyAsync(err_q, errs, (size_t)nsteps * sizeof(u64), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
     (void)hipFree(ctl); (void)hipFree(errs);
     if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_iter: %s", hipGetErrorString(e));
     const int cur = nsteps & 1;

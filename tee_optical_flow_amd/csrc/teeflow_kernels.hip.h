@@ -25,7 +25,9 @@ typedef unsigned long long u64;
 
 struct Geom {
     int w, h, pitch;
-    long long plane;  // floats per pair-plane (pitch*h)
+    long long plane;   // floats per frame plane of the pyramid (pitch*h of THIS level)
+    long long splane;  // floats between consecutive pairs in the state/constant buffers (level-0 plane at
+                       // every level, so pairs whose ping-pong parity differs never overlap across levels)
 };
 
 struct PairCtl {
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(256) void k_flow_up(StateBufs sb, const PairCtl* __
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (dx >= gd.w || dy >= gd.h) return;
     const int uc = ctl[b].ubase & 1;
-    const size_t di = (size_t)b * gd.plane + (size_t)dy * gd.pitch + dx;
-    sb.u1[uc ^ 1][di] = resize_px(sb.u1[uc] + (size_t)b * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
-    sb.u2[uc ^ 1][di] = resize_px(sb.u2[uc] + (size_t)b * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
+    const size_t di = (size_t)b * gd.splane + (size_t)dy * gd.pitch + dx;
+    sb.u1[uc ^ 1][di] = resize_px(sb.u1[uc] + (size_t)b * gs.splane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
+    sb.u2[uc ^ 1][di] = resize_px(sb.u2[uc] + (size_t)b * gs.splane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs a)
     const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
     if (x >= W || y >= H) return;
     const int uc = a.ctl[b].ubase & 1;
-    const size_t po = (size_t)b * a.g.plane, idx = (size_t)y * pitch + x;
+    const size_t po = (size_t)b * a.g.splane, idx = (size_t)y * pitch + x;
     const float u1 = a.sb.u1[uc][po + idx], u2 = a.sb.u2[uc][po + idx];
     const float* __restrict__ I0 = a.pyr + (size_t)(a.off0 + b) * a.g.plane;
     const float* __restrict__ I1 = a.pyr + (size_t)(a.off1 + b) * a.g.plane;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void k_median(MedArgs a)
     const int b = blockIdx.z >> 1, plane = blockIdx.z & 1;
     if (!pair_active(a.err + (size_t)b * a.errstride, a.it, a.thr_q)) return;
     const int uc = (a.ctl[b].ubase ^ a.utog) & 1;
-    const size_t po = (size_t)b * a.g.plane;
+    const size_t po = (size_t)b * a.g.splane;
     const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
     float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
     const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
     const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
     const int x = blockIdx.x * IT_OW + tx * 4, y = blockIdx.y * IT_OH + ty;
     const bool inr = x < W && y < H;
-    const size_t po = (size_t)b * a.g.plane;
+    const size_t po = (size_t)b * a.g.splane;
     const size_t row = po + (size_t)y * pitch + x;
 
     float u1n[4], u2n[4], p11c[4], p12c[4], p21c[4], p22c[4];
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void k_output(StateBufs sb, const PairCtl* __r
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (x >= g.w || y >= g.h) return;
     const int uc = ctl[b].ubase & 1;
-    const size_t i = (size_t)b * g.plane + (size_t)y * g.pitch + x;
+    const size_t i = (size_t)b * g.splane + (size_t)y * g.pitch + x;
     float2 v = make_float2(sb.u1[uc][i] * scale, sb.u2[uc][i] * scale);
     reinterpret_cast<float2*>(out)[((size_t)b * g.h + y) * g.w + x] = v;
 }
