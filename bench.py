@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/s of the MI355X DualTVL1 path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: every rank solves `--batch` (default 128) independent
+512x512 uint8 frame pairs (synthetic "speckle-warp v1"; pair shape of BASELINE configs[1],
+per-GPU shard size of configs[2]) with all-default DualTVL1 (lambda 0.15), inputs already resident in HBM, and --
+for N > 1 -- the (u,v) fields are all-gathered over RCCL (the one exchange step north_star names), overlapped
+with the next step's compute.  value = pairs all ranks solved / max-over-ranks wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming ceiling)
+
+
+def _gen_pair(args):
+    from tee_optical_flow_amd.synth import speckle_pair
+    seed, H, W = args
+    I0, I1, _ = speckle_pair(seed, H, W)
+    return I0, I1
+
+
+def make_inputs(seeds, H, W):
+    import multiprocessing as mp
+    n = min(8, len(seeds), os.cpu_count() or 1)
+    if n > 1:
+        with mp.get_context("spawn").Pool(n) as pool:
+            res = pool.map(_gen_pair, [(s, H, W) for s in seeds])
+    else:
+        res = [_gen_pair((s, H, W)) for s in seeds]
+    return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+
+
+def cpu_baseline(I0s, I1s, n_sample):
+    """Oracle (CPU restatement, NOT OpenCV) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    threads = O.effective_cpus()
+    O.set_num_threads(threads)
+    O.tvl1_calc(I0s[0], I1s[0])  # warm-up
+    flows = []
+    t0 = time.perf_counter()
+    for i in range(n_sample):
+        flows.append(O.tvl1_calc(I0s[i], I1s[i]))
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n_sample} of the benchmark's 512x512 pairs (seeds 0..{n_sample - 1}), 1 warm-up, "
+                      f"oracle/tvl1_oracle.c with {threads} OpenMP threads; restatement, not OpenCV"}, flows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket tvl1_iter launches with HIP events")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tee_optical_flow_amd as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, H, W = a.batch, a.size, a.size
+    seeds = list(range(rank * B, (rank + 1) * B))      # rank r owns pairs [rB, (r+1)B): no data-path exchange
+    I0s, I1s = make_inputs(seeds, H, W)
+    frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)       # [2B,H,W] u8, resident in HBM
+    flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    eng = T.DenseFlow(device_id=local_rank, max_batch=B)
+    # the engine runs on its own non-blocking HIP stream (its per-launch events are recorded there); every call is
+    # host-synchronous, so torch-side consumers (the RCCL all-gather) may start right after it returns
+    p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
+
+    pending = [None, None]
+
+    def step(k):
+        buf = k & 1
+        if pending[buf] is not None:       # the all-gather that last read this buffer must be done
+            pending[buf].wait()
+            pending[buf] = None
+        st = eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
+        if world > 1:
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf], flows[buf], async_op=True)
+        return st
+
+    def drain():
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+
+    for k in range(a.warmup):
+        step(k)
+    drain()
+    eng.set_profile(0 if a.no_profile else 1)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0}
+    for k in range(a.steps):
+        st = step(a.warmup + k)
+        acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
+        acc["total_bytes"] += st["total_bytes"]; acc["inner"] += st["inner_iters_total"]; acc["outer"] += st["outer_iters_total"]
+        acc["ms_device"] += st["ms_device"]
+    drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.set_profile(0)
+
+    out = None
+    if rank == 0:
+        pairs = world * B * a.steps
+        launches = max(acc["iter_launches"], 1)
+        avg_launch_ms = acc["iter_ms"] / launches if acc["iter_ms"] > 0 else None
+        bytes_per_launch = acc["iter_bytes"] / launches
+        achieved = (bytes_per_launch / 1e9) / (avg_launch_ms / 1e3) if avg_launch_ms else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("tvl1_iter_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "frame-pairs/sec @512x512 DualTVL1", "value": pairs / dt, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
+                                   "configs[2] per-GPU shard), speckle-warp v1 seeds rank*B..; DualTVL1 all defaults, lambda 0.15, "
+                                   "5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; inputs resident in HBM; "
+                                   + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
+                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_iter (tvl1_iter)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
+                         "launches": acc["iter_launches"], "bytes_per_px_iteration": 60},
+            "executed_inner_iterations_per_pair": acc["inner"] / (B * a.steps),
+            "executed_outer_iterations_per_pair": acc["outer"] / (B * a.steps),
+            "whole_solve_algorithmic_GBps": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
+        }
+        # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
+        lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1)
+        f1 = torch.empty((1, H, W, 2), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
+        torch.cuda.synchronize(dev)
+        tl = time.perf_counter()
+        for _ in range(10):
+            lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
+        torch.cuda.synchronize(dev)
+        out["latency_ms_single_pair"] = (time.perf_counter() - tl) / 10 * 1e3
+        lat_eng.close()
+        if world == 1 and not a.no_cpu_baseline:
+            n = min(a.cpu_sample, B)
+            cb, ref = cpu_baseline(I0s, I1s, n)
+            out["cpu_baseline"] = cb
+            got = flows[(a.warmup + a.steps - 1) & 1][:n].cpu().numpy()
+            diff = max(float(np.abs(got[i] - ref[i]).max()) for i in range(n))
+            out["parity_vs_oracle_max_abs_diff_on_cpu_sample"] = diff
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -92,8 +92,10 @@ void tf_destroy(tf_handle* h);
 int tf_set_param(tf_handle* h, int key, double value);
 int tf_get_param(tf_handle* h, int key, double* value);
 
-/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own. NULL restores. */
-int tf_set_stream(tf_handle* h, void* hip_stream);
+/* use_external != 0: run on the caller's hipStream_t `hip_stream` (NULL = the legacy default stream, which is what
+ * torch.cuda.current_stream().cuda_stream reports for torch's default stream); use_external == 0: back to the
+ * handle's own non-blocking stream.  Every tf_calc_* still returns only after its work has drained. */
+int tf_set_stream(tf_handle* h, void* hip_stream, int use_external);
 /* 0 = off; 1 = bracket every tvl1_iter launch with HIP events so tf_stats.iter_ms is filled */
 int tf_set_profile(tf_handle* h, int level);
 

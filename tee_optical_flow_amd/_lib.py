@@ -63,7 +63,7 @@ def load():
     L.tf_destroy.restype = None
     L.tf_set_param.argtypes = [vp, i32, dbl]
     L.tf_get_param.argtypes = [vp, i32, C.POINTER(dbl)]
-    L.tf_set_stream.argtypes = [vp, vp]
+    L.tf_set_stream.argtypes = [vp, vp, i32]
     L.tf_set_profile.argtypes = [vp, i32]
     L.tf_calc_pair.argtypes = [vp, vp, vp, i32, i32, vp, C.POINTER(TfStats)]
     L.tf_calc_seq.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(TfStats)]

@@ -571,11 +571,11 @@ TF_API int tf_get_param(tf_handle* h, int key, double* v)
     return TF_OK;
 }
 
-TF_API int tf_set_stream(tf_handle* h, void* hip_stream)
+TF_API int tf_set_stream(tf_handle* h, void* hip_stream, int use_external)
 {
     if (!h) return TF_ERR_INVALID_ARG;
     HIPC(h, hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = use_external ? (hipStream_t)hip_stream : h->own_stream;
     return TF_OK;
 }
 

@@ -84,9 +84,10 @@ class DenseFlow:
         raise AttributeError(name)
 
     # ---- engine controls -----------------------------------------------------------------------
-    def set_stream(self, hip_stream_ptr):
-        """Run on a caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
-        _lib.check(self._L.tf_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)), self._h, "tf_set_stream")
+    def set_stream(self, hip_stream_ptr, external=True):
+        """Run on a caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream, 0 = legacy default stream);
+        external=False returns to the handle's own non-blocking stream."""
+        _lib.check(self._L.tf_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0), 1 if external else 0), self._h, "tf_set_stream")
 
     def set_profile(self, level):
         _lib.check(self._L.tf_set_profile(self._h, int(level)), self._h, "tf_set_profile")
