@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "tf_abi_version", "tf_device_count", "tf_default_params", "tf_create", "tf_destroy", "tf_set_param",
     "tf_get_param", "tf_set_stream", "tf_set_profile", "tf_calc_pair", "tf_calc_seq", "tf_calc_pairs",
     "tf_calc_pairs_device", "tf_calc_seq_device", "tf_get_iters", "tf_last_error",
-    "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
+    "tf_set_tuning", "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
 ]
 
 
@@ -65,6 +65,7 @@ def load():
     L.tf_get_param.argtypes = [vp, i32, C.POINTER(dbl)]
     L.tf_set_stream.argtypes = [vp, vp, i32]
     L.tf_set_profile.argtypes = [vp, i32]
+    L.tf_set_tuning.argtypes = [vp, C.c_char_p, i32]
     L.tf_calc_pair.argtypes = [vp, vp, vp, i32, i32, vp, C.POINTER(TfStats)]
     L.tf_calc_seq.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
     L.tf_calc_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.POINTER(TfStats)]

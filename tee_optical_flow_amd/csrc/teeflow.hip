@@ -67,6 +67,10 @@ struct tf_handle {
     std::vector<int> last_iters; int last_pairs = 0, last_nlev = 0, last_warps = 0;
     // per-call accumulators
     unsigned long long iter_launches = 0;
+    // tuning knobs (tf_set_tuning)
+    int iter_variant = 1;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows) when W <= 1024
+    int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
+    int probe_cadence = 0;       // 0 = automatic
 };
 
 namespace {
@@ -193,6 +197,25 @@ struct StageTotals {
     double iter_bytes = 0, total_bytes = 0;
 };
 
+// launch one tvl1_iter step for pairs [0,B) in the configured kernel form
+void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
+{
+    const Geom& g = ia.g;
+    if (h->iter_variant == 1 && g.w <= 1024) {
+        const int QX = (g.w + 3) / 4, RY = 256 / QX;
+        long long n = (long long)g.h * B / ((long long)h->strip_blocks * RY);
+        if (n < 2) n = 2;
+        if (n > 16) n = 16;
+        const int R = RY * (int)n;
+        const int LW = QX * 4 + 4;
+        const size_t shmem = (size_t)(8 + 8 * RY * LW + 2 * RY * QX) * sizeof(float);
+        hipLaunchKernelGGL(k_iter_rows, dim3((g.h + R - 1) / R, 1, B), dim3(256), shmem, s, ia, R, QX, RY);
+    } else {
+        const dim3 gi((g.w + IT_OW - 1) / IT_OW, (g.h + IT_OH - 1) / IT_OH, B);
+        hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, s, ia);
+    }
+}
+
 // one (level, warp) stage for pairs [0,B)
 int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 {
@@ -216,12 +239,11 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     MedArgs ma;
     ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
 
-    const dim3 gi((g.w + IT_OW - 1) / IT_OW, (g.h + IT_OH - 1) / IT_OH, B);
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     // probe cadence: every iteration for large batches (a probe costs ~a few us of stream time),
     // sparser when one iteration itself is only a few us
     const double est_iter_us = (double)B * g.w * g.h * 60.0 / 4.0e6;
-    const int cadence = est_iter_us >= 100.0 ? 1 : (est_iter_us >= 25.0 ? 2 : 4);
+    const int cadence = h->probe_cadence > 0 ? h->probe_cadence : (est_iter_us >= 100.0 ? 1 : (est_iter_us >= 25.0 ? 2 : 4));
 
     std::deque<unsigned> pending;
     int utog = 0, ptog = 0;
@@ -242,10 +264,10 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
             }
             ProfEv& pe = h->prof_pool[h->prof_used++];
             HIPC(h, hipEventRecord(pe.a, s));
-            hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, s, ia);
+            launch_iter(h, ia, B, s);
             HIPC(h, hipEventRecord(pe.b, s));
         } else {
-            hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, s, ia);
+            launch_iter(h, ia, B, s);
         }
         ++h->iter_launches;
         ++utog; ++ptog; ++it;
@@ -579,6 +601,17 @@ TF_API int tf_set_stream(tf_handle* h, void* hip_stream, int use_external)
     return TF_OK;
 }
 
+TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
+{
+    if (!h || !name) return TF_ERR_INVALID_ARG;
+    const std::string n(name);
+    if (n == "iter_variant") h->iter_variant = value;
+    else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
+    else if (n == "probe_cadence") h->probe_cadence = value;
+    else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
+    return TF_OK;
+}
+
 TF_API int tf_set_profile(tf_handle* h, int level)
 {
     if (!h) return TF_ERR_INVALID_ARG;
@@ -752,10 +785,9 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     }
     ia.ctl = ctl; ia.err = errs; ia.errstride = nsteps + 1; ia.thr_q = -1.0; ia.g = g;
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
-    const dim3 gi((g.w + IT_OW - 1) / IT_OW, (g.h + IT_OH - 1) / IT_OH, 1);
     for (int it = 0; it < nsteps; ++it) {
         ia.it = it; ia.utog = it; ia.ptog = it; ia.pzero = (p_is_zero && it == 0) ? 1 : 0;
-        hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, h->stream, ia);
+        launch_iter(h, ia, 1, h->stream);
     }
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && err_q && nsteps > 0) {

@@ -403,6 +403,206 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// tvl1_iter, row-strip form (the one the solver launches for W <= 1024): same arithmetic as k_iter,
+// different traffic shape.  A block owns R full-width rows of one pair and marches down them RY rows
+// per step (thread = one float4 quad of one row).  Full-width rows mean every 128-B line of every plane
+// is fetched exactly once per launch (no x halo; the 64x16 tiles of k_iter start at 240-B offsets and
+// fetch ~1.8x the algorithmic bytes at the fabric), and the only re-computation is one halo row per
+// strip for the forward difference in y.  Neighbour exchange (p12/p22 of the row above, p11/p21 of the
+// quad to the left, u' of the quad to the right and of the row below) goes through LDS; the dual
+// update of a row is deferred by one step until the u' row below it exists.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tv_u_px(float l_t, float theta, float u1k, float u2k, float wx, float wy, float r,
+                                        float p11, float p11l, float p12, float p12u, float p21, float p21l, float p22,
+                                        float p22u, bool ytop, bool xleft, float& u1n, float& u2n)
+{
+    const float Ix2 = wx * wx, Iy2 = wy * wy;
+    const float grad = Ix2 + Iy2;
+    const float rho = r + (wx * u1k + wy * u2k);
+    const float lg = l_t * grad;
+    float d1 = 0.f, d2 = 0.f;
+    if (rho < -lg) { d1 = l_t * wx; d2 = l_t * wy; }
+    else if (rho > lg) { d1 = -l_t * wx; d2 = -l_t * wy; }
+    else if (grad > FLT_EPSILON) { const float fi = -rho / grad; d1 = fi * wx; d2 = fi * wy; }
+    const float v1 = u1k + d1, v2 = u2k + d2;
+    float div1, div2;
+    if (!ytop && !xleft) { div1 = (p11 - p11l) + (p12 - p12u); div2 = (p21 - p21l) + (p22 - p22u); }
+    else if (ytop && !xleft) { div1 = (p11 - p11l) + p12; div2 = (p21 - p21l) + p22; }
+    else if (xleft && !ytop) { div1 = (p11 + p12) - p12u; div2 = (p21 + p22) - p22u; }
+    else { div1 = p11 + p12; div2 = p21 + p22; }
+    u1n = v1 + theta * div1;
+    u2n = v2 + theta * div2;
+}
+
+__device__ __forceinline__ u64 tv_err_q(float u1n, float u1k, float u2n, float u2k)
+{
+    const float e1 = u1n - u1k, e2 = u2n - u2k;
+    const float t = e1 * e1 + e2 * e2;
+    return (u64)__float2ll_rn(fminf(t, ERR_CAP_F) * ERR_SCALE_F);
+}
+
+__device__ __forceinline__ void tv_p_px(float taut, float ux, float uy, float pa, float pb, float& oa, float& ob)
+{
+    const float ng = 1.0f + taut * hypot_exact(ux, uy);
+    oa = (pa + taut * ux) / ng;
+    ob = (pb + taut * uy) / ng;
+}
+
+__global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, int RY)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LW = QX * 4 + 4;
+    u64* sred = reinterpret_cast<u64*>(smem);      // 4 x u64 = 32 B, keeps the float arrays 16-B aligned
+    float* su1 = smem + 8;                         // [2][RY][LW]   u1' rows of this / the previous step
+    float* su2 = su1 + 2 * RY * LW;
+    float* sp12 = su2 + 2 * RY * LW;               // [2][RY][LW]   old p12 rows (the row below reads them)
+    float* sp22 = sp12 + 2 * RY * LW;
+    float* sp11w = sp22 + 2 * RY * LW;             // [RY][QX]      last element of each quad of old p11
+    float* sp21w = sp11w + RY * QX;
+
+    const int b = blockIdx.z;
+    u64* errb = a.err + (size_t)b * a.errstride;
+    if (!pair_active(errb, a.it, a.thr_q)) return;   // block-uniform
+    const PairCtl c = a.ctl[b];
+    const int uc = (c.ubase ^ a.utog) & 1, pc = (c.pbase ^ a.ptog) & 1;
+    const int tid = threadIdx.x;
+    const int ty = tid / QX, tx = tid - ty * QX;
+    const bool lane_on = ty < RY;
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    const int x = tx * 4;
+    const int y0 = blockIdx.x * R;
+    const int nsteps = R / RY;
+    const size_t po = (size_t)b * a.g.splane;
+
+    const float* __restrict__ gu1 = a.sb.u1[uc] + po;
+    const float* __restrict__ gu2 = a.sb.u2[uc] + po;
+    const float* __restrict__ g11 = a.sb.p11[pc] + po;
+    const float* __restrict__ g12 = a.sb.p12[pc] + po;
+    const float* __restrict__ g21 = a.sb.p21[pc] + po;
+    const float* __restrict__ g22 = a.sb.p22[pc] + po;
+    const float* __restrict__ gwx = a.wx + po;
+    const float* __restrict__ gwy = a.wy + po;
+    const float* __restrict__ grh = a.rho + po;
+
+    // state of the previous step's row, waiting for the u' row below it
+    float pu1[4] = {0, 0, 0, 0}, pu2[4] = {0, 0, 0, 0}, q11[4], q12[4], q21[4], q22[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q11[i] = q12[i] = q21[i] = q22[i] = 0.f;
+    bool prev_out = false;
+    int prev_y = 0;
+    u64 q = 0;
+
+    // software pipeline: the 9 plane loads of step s+1 are issued before step s computes
+    float4 n_u1, n_u2, n_wx, n_wy, n_r, n_11, n_12, n_21, n_22;
+    n_u1 = n_u2 = n_wx = n_wy = n_r = n_11 = n_12 = n_21 = n_22 = make_float4(0, 0, 0, 0);
+    {
+        const int y = y0 + ty;
+        if (lane_on && y < H) {
+            const size_t row = (size_t)y * pitch + x;
+            n_u1 = ld4(gu1 + row); n_u2 = ld4(gu2 + row);
+            n_wx = ld4(gwx + row); n_wy = ld4(gwy + row); n_r = ld4(grh + row);
+            if (!a.pzero) { n_11 = ld4(g11 + row); n_12 = ld4(g12 + row); n_21 = ld4(g21 + row); n_22 = ld4(g22 + row); }
+        }
+    }
+    for (int s = 0; s <= nsteps; ++s) {
+        const int cur = s & 1;
+        const int y = y0 + s * RY + ty;
+        const bool valid = lane_on && y < H && (s < nsteps || ty == 0);   // step nsteps = the halo row (u' only)
+        const bool is_out = lane_on && s < nsteps && y < H;
+        const size_t row = (size_t)y * pitch + x;
+        const float4 u1q = n_u1, u2q = n_u2, wxq = n_wx, wyq = n_wy, rq = n_r, a11 = n_11, a12 = n_12, a21 = n_21, a22 = n_22;
+        {
+            const int yn = y + RY;
+            const bool nvalid = lane_on && yn < H && (s + 1 < nsteps || (s + 1 == nsteps && ty == 0));
+            if (nvalid) {
+                const size_t rown = (size_t)yn * pitch + x;
+                n_u1 = ld4(gu1 + rown); n_u2 = ld4(gu2 + rown);
+                n_wx = ld4(gwx + rown); n_wy = ld4(gwy + rown); n_r = ld4(grh + rown);
+                if (!a.pzero) { n_11 = ld4(g11 + rown); n_12 = ld4(g12 + rown); n_21 = ld4(g21 + rown); n_22 = ld4(g22 + rown); }
+            }
+        }
+        if (valid) {
+            st4(sp12 + (cur * RY + ty) * LW + x, a12);
+            st4(sp22 + (cur * RY + ty) * LW + x, a22);
+            sp11w[ty * QX + tx] = a11.w;
+            sp21w[ty * QX + tx] = a21.w;
+        }
+        __syncthreads();
+        float u1n[4] = {0, 0, 0, 0}, u2n[4] = {0, 0, 0, 0};
+        if (valid) {
+            float4 up12 = make_float4(0, 0, 0, 0), up22 = up12;
+            if (y > 0) {
+                if (ty > 0) { up12 = ld4(sp12 + (cur * RY + ty - 1) * LW + x); up22 = ld4(sp22 + (cur * RY + ty - 1) * LW + x); }
+                else if (s > 0) { up12 = ld4(sp12 + ((cur ^ 1) * RY + RY - 1) * LW + x); up22 = ld4(sp22 + ((cur ^ 1) * RY + RY - 1) * LW + x); }
+                else if (!a.pzero) { up12 = ld4(g12 + row - pitch); up22 = ld4(g22 + row - pitch); }
+            }
+            float l11 = 0.f, l21 = 0.f;
+            if (tx > 0) { l11 = sp11w[ty * QX + tx - 1]; l21 = sp21w[ty * QX + tx - 1]; }
+            const float u1k[4] = {u1q.x, u1q.y, u1q.z, u1q.w}, u2k[4] = {u2q.x, u2q.y, u2q.z, u2q.w};
+            const float wxv[4] = {wxq.x, wxq.y, wxq.z, wxq.w}, wyv[4] = {wyq.x, wyq.y, wyq.z, wyq.w};
+            const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
+            const float c11[4] = {a11.x, a11.y, a11.z, a11.w}, c12[4] = {a12.x, a12.y, a12.z, a12.w};
+            const float c21[4] = {a21.x, a21.y, a21.z, a21.w}, c22[4] = {a22.x, a22.y, a22.z, a22.w};
+            const float q12u[4] = {up12.x, up12.y, up12.z, up12.w}, q22u[4] = {up22.x, up22.y, up22.z, up22.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tv_u_px(a.l_t, a.theta, u1k[i], u2k[i], wxv[i], wyv[i], rv[i], c11[i], i == 0 ? l11 : c11[i - 1], c12[i], q12u[i],
+                        c21[i], i == 0 ? l21 : c21[i - 1], c22[i], q22u[i], y == 0, x + i == 0, u1n[i], u2n[i]);
+                if (is_out && x + i < W) q += tv_err_q(u1n[i], u1k[i], u2n[i], u2k[i]);
+            }
+            st4(su1 + (cur * RY + ty) * LW + x, make_float4(u1n[0], u1n[1], u1n[2], u1n[3]));
+            st4(su2 + (cur * RY + ty) * LW + x, make_float4(u2n[0], u2n[1], u2n[2], u2n[3]));
+            // keep this row's old p for its deferred dual update (after the previous row's update below)
+        }
+        __syncthreads();
+        if (prev_out) {
+            // dual update of the previous step's row: forward differences of u' (0 in the last column / row)
+            const float* d1 = ty < RY - 1 ? su1 + ((cur ^ 1) * RY + ty + 1) * LW + x : su1 + (cur * RY) * LW + x;
+            const float* d2 = ty < RY - 1 ? su2 + ((cur ^ 1) * RY + ty + 1) * LW + x : su2 + (cur * RY) * LW + x;
+            const bool lastrow = prev_y >= H - 1;
+            float4 dn1 = make_float4(0, 0, 0, 0), dn2 = dn1;
+            if (!lastrow) { dn1 = ld4(d1); dn2 = ld4(d2); }
+            float r1 = 0.f, r2 = 0.f;
+            if (x + 4 < W) { r1 = su1[((cur ^ 1) * RY + ty) * LW + x + 4]; r2 = su2[((cur ^ 1) * RY + ty) * LW + x + 4]; }
+            const float dv1[4] = {dn1.x, dn1.y, dn1.z, dn1.w}, dv2[4] = {dn2.x, dn2.y, dn2.z, dn2.w};
+            float o11[4], o12[4], o21[4], o22[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xi = x + i;
+                const float n1 = i < 3 ? pu1[i + 1] : r1, n2 = i < 3 ? pu2[i + 1] : r2;
+                const float u1x = xi < W - 1 ? n1 - pu1[i] : 0.f;
+                const float u2x = xi < W - 1 ? n2 - pu2[i] : 0.f;
+                const float u1y = !lastrow ? dv1[i] - pu1[i] : 0.f;
+                const float u2y = !lastrow ? dv2[i] - pu2[i] : 0.f;
+                tv_p_px(a.taut, u1x, u1y, q11[i], q12[i], o11[i], o12[i]);
+                tv_p_px(a.taut, u2x, u2y, q21[i], q22[i], o21[i], o22[i]);
+            }
+            const size_t prow = po + (size_t)prev_y * pitch + x;
+            st4(a.sb.u1[uc ^ 1] + prow, make_float4(pu1[0], pu1[1], pu1[2], pu1[3]));
+            st4(a.sb.u2[uc ^ 1] + prow, make_float4(pu2[0], pu2[1], pu2[2], pu2[3]));
+            st4(a.sb.p11[pc ^ 1] + prow, make_float4(o11[0], o11[1], o11[2], o11[3]));
+            st4(a.sb.p12[pc ^ 1] + prow, make_float4(o12[0], o12[1], o12[2], o12[3]));
+            st4(a.sb.p21[pc ^ 1] + prow, make_float4(o21[0], o21[1], o21[2], o21[3]));
+            st4(a.sb.p22[pc ^ 1] + prow, make_float4(o22[0], o22[1], o22[2], o22[3]));
+        }
+        // rotate: this step's row becomes the pending one
+        prev_out = is_out;
+        prev_y = y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pu1[i] = u1n[i]; pu2[i] = u2n[i]; }
+        q11[0] = a11.x; q11[1] = a11.y; q11[2] = a11.z; q11[3] = a11.w;
+        q12[0] = a12.x; q12[1] = a12.y; q12[2] = a12.z; q12[3] = a12.w;
+        q21[0] = a21.x; q21[1] = a21.y; q21[2] = a21.z; q21[3] = a21.w;
+        q22[0] = a22.x; q22[1] = a22.y; q22[2] = a22.z; q22[3] = a22.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if ((tid & 63) == 0) sred[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) atomicAdd(&errb[a.it], sred[0] + sred[1] + sred[2] + sred[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // control kernels (a few threads; they keep the stop/continue decisions on the device)
 // ---------------------------------------------------------------------------------------------
 // number of pairs still iterating after `it_done` iterations -> *out

@@ -92,6 +92,10 @@ class DenseFlow:
     def set_profile(self, level):
         _lib.check(self._L.tf_set_profile(self._h, int(level)), self._h, "tf_set_profile")
 
+    def set_tuning(self, name, value):
+        """Implementation knobs (never change results): iter_variant, strip_blocks, probe_cadence."""
+        _lib.check(self._L.tf_set_tuning(self._h, name.encode(), int(value)), self._h, "tf_set_tuning")
+
     def _finish(self, st):
         self.last_stats = st.as_dict()
 
