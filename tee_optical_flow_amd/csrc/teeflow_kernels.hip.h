@@ -492,36 +492,18 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
     int prev_y = 0;
     u64 q = 0;
 
-    // software pipeline: the 9 plane loads of step s+1 are issued before step s computes
-    float4 n_u1, n_u2, n_wx, n_wy, n_r, n_11, n_12, n_21, n_22;
-    n_u1 = n_u2 = n_wx = n_wy = n_r = n_11 = n_12 = n_21 = n_22 = make_float4(0, 0, 0, 0);
-    {
-        const int y = y0 + ty;
-        if (lane_on && y < H) {
-            const size_t row = (size_t)y * pitch + x;
-            n_u1 = ld4(gu1 + row); n_u2 = ld4(gu2 + row);
-            n_wx = ld4(gwx + row); n_wy = ld4(gwy + row); n_r = ld4(grh + row);
-            if (!a.pzero) { n_11 = ld4(g11 + row); n_12 = ld4(g12 + row); n_21 = ld4(g21 + row); n_22 = ld4(g22 + row); }
-        }
-    }
     for (int s = 0; s <= nsteps; ++s) {
         const int cur = s & 1;
         const int y = y0 + s * RY + ty;
         const bool valid = lane_on && y < H && (s < nsteps || ty == 0);   // step nsteps = the halo row (u' only)
         const bool is_out = lane_on && s < nsteps && y < H;
         const size_t row = (size_t)y * pitch + x;
-        const float4 u1q = n_u1, u2q = n_u2, wxq = n_wx, wyq = n_wy, rq = n_r, a11 = n_11, a12 = n_12, a21 = n_21, a22 = n_22;
-        {
-            const int yn = y + RY;
-            const bool nvalid = lane_on && yn < H && (s + 1 < nsteps || (s + 1 == nsteps && ty == 0));
-            if (nvalid) {
-                const size_t rown = (size_t)yn * pitch + x;
-                n_u1 = ld4(gu1 + rown); n_u2 = ld4(gu2 + rown);
-                n_wx = ld4(gwx + rown); n_wy = ld4(gwy + rown); n_r = ld4(grh + rown);
-                if (!a.pzero) { n_11 = ld4(g11 + rown); n_12 = ld4(g12 + rown); n_21 = ld4(g21 + rown); n_22 = ld4(g22 + rown); }
-            }
-        }
+        float4 u1q, u2q, wxq, wyq, rq, a11, a12, a21, a22;
+        u1q = u2q = wxq = wyq = rq = a11 = a12 = a21 = a22 = make_float4(0, 0, 0, 0);
         if (valid) {
+            u1q = ld4(gu1 + row); u2q = ld4(gu2 + row);
+            wxq = ld4(gwx + row); wyq = ld4(gwy + row); rq = ld4(grh + row);
+            if (!a.pzero) { a11 = ld4(g11 + row); a12 = ld4(g12 + row); a21 = ld4(g21 + row); a22 = ld4(g22 + row); }
             st4(sp12 + (cur * RY + ty) * LW + x, a12);
             st4(sp22 + (cur * RY + ty) * LW + x, a22);
             sp11w[ty * QX + tx] = a11.w;
