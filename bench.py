@@ -123,7 +123,6 @@ def main():
     for k in range(a.warmup):
         step(k)
     drain()
-    eng.set_profile(0 if a.no_profile else 1)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -132,7 +131,6 @@ def main():
     acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0}
     for k in range(a.steps):
         st = step(a.warmup + k)
-        acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
         acc["total_bytes"] += st["total_bytes"]; acc["inner"] += st["inner_iters_total"]; acc["outer"] += st["outer_iters_total"]
         acc["ms_device"] += st["ms_device"]
     drain()
@@ -145,7 +143,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    eng.set_profile(0)
+    # Roofline leg: the SAME K steps again with every tvl1_iter launch bracketed by a HIP event pair on the engine's
+    # stream.  Kept out of the timed region above because ~1200 event records per step cost ~8% of a step.
+    if not a.no_profile:
+        eng.set_profile(1)
+        for k in range(a.steps):
+            st = step(a.warmup + a.steps + k)
+            acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
+        drain()
+        torch.cuda.synchronize(dev)
+        eng.set_profile(0)
 
     out = None
     if rank == 0:
@@ -174,7 +181,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_iter (tvl1_iter)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
-                         "launches": acc["iter_launches"], "bytes_per_px_iteration": 60},
+                         "launches": acc["iter_launches"], "bytes_per_px_iteration": 60,
+                         "measured_on": f"{a.steps} instrumented repeats of the timed steps (one HIP event pair per launch, engine stream)"},
             "executed_inner_iterations_per_pair": acc["inner"] / (B * a.steps),
             "executed_outer_iterations_per_pair": acc["outer"] / (B * a.steps),
             "whole_solve_algorithmic_GBps": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
@@ -195,7 +203,8 @@ def main():
             n = min(a.cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n)
             out["cpu_baseline"] = cb
-            got = flows[(a.warmup + a.steps - 1) & 1][:n].cpu().numpy()
+            last = a.warmup + a.steps - 1 + (0 if a.no_profile else a.steps)
+            got = flows[last & 1][:n].cpu().numpy()
             diff = max(float(np.abs(got[i] - ref[i]).max()) for i in range(n))
             out["parity_vs_oracle_max_abs_diff_on_cpu_sample"] = diff
     eng.close()

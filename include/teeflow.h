@@ -130,7 +130,8 @@ int tf_device_count(void);
 /* ---- kernel-level test hooks (dense host arrays, one image; used by tests/ to compare each kernel
  *      with the oracle bit for bit; not part of the drop-in surface) -------------------------------- */
 /* implementation knobs for experiments: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips),
- * "strip_blocks" (target blocks per tvl1_iter launch), "probe_cadence" (0 = automatic). Results never change. */
+ * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
+ * stop reports). Results never change. */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 int tf_dbg_pyramid(tf_handle* h, const uint8_t* img, int H, int W, int level, float* out, int* ow, int* oh);
 int tf_dbg_resize(tf_handle* h, const float* src, int sw, int sh, float* dst, int dw, int dh,

@@ -8,8 +8,8 @@
 //   pyramid -> for level (coarse..fine): for warp: k_warp, then [median every `inner` iterations,
 //   tvl1_iter] until each pair's own convergence test stops it.
 // The stop decision lives on the device (per-pair error slots, blocks of stopped pairs exit at once);
-// the host only learns "nobody is iterating any more" through small lagged probes, so it never
-// stalls the stream inside the iteration budget.
+// each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
+// launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
 #include "../../include/teeflow.h"
 
@@ -27,8 +27,8 @@
 namespace {
 
 constexpr int MAXLEV = 64;
-constexpr int PROBE_RING = 32;
-constexpr int PROBE_LAG = 2;          // host runs at most this many probes ahead of the GPU's answers
+constexpr int SLOT_RING = 1024;       // host-mapped words the tvl1_iter launches publish their active-pair count to
+constexpr int DEFAULT_LAG = 3;        // the host enqueues at most this many launches beyond the last answer it has read
 constexpr int DEFAULT_MAX_BATCH = 128;
 
 thread_local std::string g_create_error;
@@ -53,9 +53,8 @@ struct tf_handle {
     PairCtl* ctl = nullptr;
     u64* errs = nullptr; int errstride = 0;
     int* iters_dev = nullptr; size_t iters_cap = 0;
-    int* probe_dev = nullptr; int* probe_host = nullptr;
-    hipEvent_t probe_ev[PROBE_RING] = {};
-    unsigned probe_seq = 0;
+    volatile int* slots_host = nullptr; int* slots_dev = nullptr;   // fine-grained pinned ring (SLOT_RING ints)
+    unsigned launch_seq = 0;
     float* tab = nullptr;
     // staging for the host-pointer API
     uint8_t* st_u8 = nullptr; size_t st_u8_bytes = 0;
@@ -70,7 +69,7 @@ struct tf_handle {
     // tuning knobs (tf_set_tuning)
     int iter_variant = 1;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows) when W <= 1024
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
-    int probe_cadence = 0;       // 0 = automatic
+    int lag = DEFAULT_LAG;
 };
 
 namespace {
@@ -90,6 +89,11 @@ int fail(tf_handle* h, int code, const char* fmt, ...)
             return fail(h, e_ == hipErrorOutOfMemory ? TF_ERR_NOMEM : TF_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
                         hipGetErrorString(e_), __FILE__, __LINE__);                                \
     } while (0)
+
+inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int cv_round_d(double v) { return (int)lrint(v); }   // saturate_cast<int>(double): nearest-even
@@ -240,14 +244,11 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
-    // probe cadence: every iteration for large batches (a probe costs ~a few us of stream time),
-    // sparser when one iteration itself is only a few us
-    const double est_iter_us = (double)B * g.w * g.h * 60.0 / 4.0e6;
-    const int cadence = h->probe_cadence > 0 ? h->probe_cadence : (est_iter_us >= 100.0 ? 1 : (est_iter_us >= 25.0 ? 2 : 4));
-
-    std::deque<unsigned> pending;
+    ia.B = B;
     int utog = 0, ptog = 0;
     bool stop = false;
+    const unsigned seq0 = h->launch_seq;
+    unsigned checked = seq0;          // launches [seq0, checked) have been read back
     for (int it = 0; it < total && !stop;) {
         if (it % inner == 0 && P.median_filtering > 1) {
             ma.it = it; ma.utog = utog;
@@ -255,6 +256,9 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
             else hipLaunchKernelGGL(k_median<3>, gm, dim3(256), 0, s, ma);
             ++utog;
         }
+        const unsigned q = h->launch_seq++;
+        h->slots_host[q % SLOT_RING] = -1;
+        ia.host_slot = h->slots_dev + q % SLOT_RING;
         ia.it = it; ia.utog = utog; ia.ptog = ptog; ia.pzero = (wi == 0 && it == 0) ? 1 : 0;
         if (h->profile) {
             if (h->prof_used == h->prof_pool.size()) {
@@ -271,27 +275,22 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
         }
         ++h->iter_launches;
         ++utog; ++ptog; ++it;
-        if (it < total && it % cadence == 0) {
-            const unsigned slot = h->probe_seq++ % PROBE_RING;
-            hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), 0, s, h->errs, h->errstride, B, it, thr_q, h->probe_dev + slot);
-            HIPC(h, hipMemcpyAsync(h->probe_host + slot, h->probe_dev + slot, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPC(h, hipEventRecord(h->probe_ev[slot], s));
-            pending.push_back(slot);
-        }
-        while (!pending.empty()) {
-            const unsigned slot = pending.front();
-            if ((int)pending.size() > PROBE_LAG) HIPC(h, hipEventSynchronize(h->probe_ev[slot]));
-            else {
-                hipError_t qe = hipEventQuery(h->probe_ev[slot]);
-                if (qe == hipErrorNotReady) break;
-                if (qe != hipSuccess) return fail(h, TF_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(qe));
+        // read back what earlier launches of this stage published: never more than `lag` launches unread
+        while (checked <= q) {
+            int v = h->slots_host[checked % SLOT_RING];
+            if (v < 0) {
+                if (q - checked < (unsigned)h->lag) break;        // not there yet, and we may still run ahead
+                const double t0 = now_ms();
+                while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
+                    if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "tvl1_iter launch %u never reported (GPU hang?)", checked);
+                    if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
+                        return fail(h, TF_ERR_HIP, "stream drained but launch %u did not report", checked);
+                }
             }
-            pending.pop_front();
-            if (h->probe_host[slot] == 0) { stop = true; break; }
+            ++checked;
+            if (v == 0) { stop = true; break; }   // nobody entered that iteration active: the rest would be no-ops
         }
     }
-    // any probe still in flight must land before its ring slot can be reused
-    if (!pending.empty()) HIPC(h, hipEventSynchronize(h->probe_ev[pending.back()]));
     hipLaunchKernelGGL(k_stage_end, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
                        total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
     return TF_OK;
@@ -327,11 +326,6 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
     hipLaunchKernelGGL(k_output, grid64x4(g0, B), dim3(256), 0, s, h->sb, h->ctl, g0, scale, dflow);
     HIPC(h, hipGetLastError());
     return TF_OK;
-}
-
-double now_ms()
-{
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // algorithmic (compulsory) HBM bytes of one solved pair from its executed iteration counts
@@ -507,9 +501,14 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-    for (auto& ev : h->probe_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc(&h->probe_dev, PROBE_RING * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipHostMalloc(&h->probe_host, PROBE_RING * sizeof(int))) != hipSuccess) return bail(e, "hipHostMalloc");
+    {
+        void* hp = nullptr; void* dp = nullptr;
+        if ((e = hipHostMalloc(&hp, SLOT_RING * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e, "hipHostMalloc");
+        h->slots_host = (volatile int*)hp;
+        if ((e = hipHostGetDevicePointer(&dp, hp, 0)) != hipSuccess) return bail(e, "hipHostGetDevicePointer");
+        h->slots_dev = (int*)dp;
+        for (int i = 0; i < SLOT_RING; ++i) h->slots_host[i] = -1;
+    }
     // bicubic coefficient table of cv::remap (interpolateCubic, A = -0.75, 1/32-px steps), float arithmetic
     float tab[128];
     {
@@ -537,10 +536,8 @@ TF_API void tf_destroy(tf_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_buffers(h);
     if (h->tab) (void)hipFree(h->tab);
-    if (h->probe_dev) (void)hipFree(h->probe_dev);
-    if (h->probe_host) (void)hipHostFree(h->probe_host);
+    if (h->slots_host) (void)hipHostFree((void*)h->slots_host);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : h->probe_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& pe : h->prof_pool) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -607,7 +604,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     const std::string n(name);
     if (n == "iter_variant") h->iter_variant = value;
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
-    else if (n == "probe_cadence") h->probe_cadence = value;
+    else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
 }
@@ -783,7 +780,7 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
         ia.sb.u1[k] = s[0 + k].p; ia.sb.u2[k] = s[2 + k].p; ia.sb.p11[k] = s[4 + k].p;
         ia.sb.p12[k] = s[6 + k].p; ia.sb.p21[k] = s[8 + k].p; ia.sb.p22[k] = s[10 + k].p;
     }
-    ia.ctl = ctl; ia.err = errs; ia.errstride = nsteps + 1; ia.thr_q = -1.0; ia.g = g;
+    ia.ctl = ctl; ia.err = errs; ia.errstride = nsteps + 1; ia.thr_q = -1.0; ia.g = g; ia.host_slot = nullptr; ia.B = 1;
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
     for (int it = 0; it < nsteps; ++it) {
         ia.it = it; ia.utog = it; ia.ptog = it; ia.pzero = (p_is_zero && it == 0) ? 1 : 0;

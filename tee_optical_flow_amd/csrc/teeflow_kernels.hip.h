@@ -274,7 +274,23 @@ struct IterArgs {
     int utog, ptog, pzero;
     Geom g;
     float l_t, theta, taut;
+    int* host_slot;   // host-mapped word: block 0 publishes how many pairs are still iterating at this launch
+    int B;
 };
+
+// Block 0 / wave 0 tells the host how many of the B pairs enter iteration `it` active, through fine-grained
+// host memory.  The host reads it a few launches later (never blocking the stream) to stop enqueuing a stage.
+__device__ __forceinline__ void publish_active_count(const IterArgs& a)
+{
+    if (a.host_slot && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
+        int c = 0;
+        for (int b2 = threadIdx.x; b2 < a.B; b2 += 64)
+            c += pair_active(a.err + (size_t)b2 * a.errstride, a.it, a.thr_q) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (threadIdx.x == 0) __hip_atomic_store(a.host_slot, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 __device__ __forceinline__ float hypot_exact(float a, float b)
 {
@@ -287,6 +303,7 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
     __shared__ __attribute__((aligned(16))) float su1[IT_TH][IT_TW + 4];
     __shared__ __attribute__((aligned(16))) float su2[IT_TH][IT_TW + 4];
     __shared__ u64 sred[4];
+    publish_active_count(a);
     const int b = blockIdx.z;
     u64* errb = a.err + (size_t)b * a.errstride;
     if (!pair_active(errb, a.it, a.thr_q)) return;   // block-uniform
@@ -460,6 +477,7 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
     float* sp11w = sp22 + 2 * RY * LW;             // [RY][QX]      last element of each quad of old p11
     float* sp21w = sp11w + RY * QX;
 
+    publish_active_count(a);
     const int b = blockIdx.z;
     u64* errb = a.err + (size_t)b * a.errstride;
     if (!pair_active(errb, a.it, a.thr_q)) return;   // block-uniform
@@ -587,20 +605,6 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
 // ---------------------------------------------------------------------------------------------
 // control kernels (a few threads; they keep the stop/continue decisions on the device)
 // ---------------------------------------------------------------------------------------------
-// number of pairs still iterating after `it_done` iterations -> *out
-__global__ void k_probe(const u64* __restrict__ err, int errstride, int B, int it_done, double thr_q, int* out)
-{
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    int c = 0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x)
-        c += pair_active(err + (size_t)b * errstride, it_done, thr_q) ? 1 : 0;
-    if (c) atomicAdd(&cnt, c);
-    __syncthreads();
-    if (threadIdx.x == 0) *out = cnt;
-}
-
 // end of one (level, warp) stage: executed iteration counts -> stats; advance the ping-pong bases
 __global__ void k_stage_end(const u64* __restrict__ err, int errstride, PairCtl* ctl, int* iters, int B,
                             int total, int inner, int median_on, double thr_q, int level, int warp, int nlev, int warps)
