@@ -1,0 +1,104 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol include/teeflow.h declares, the ctypes
+struct layouts equal the C ones, and the product path fails LOUDLY (never falls back) when no device is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "teeflow.h")
+
+
+def _declared_functions():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tf_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_cites_reference_interfaces():
+    txt = open(HDR).read()
+    for needle in ("calculate_optical_flow.py:577", "calculate_optical_flow.py:578", "calculate_optical_flow.py:642",
+                   "calculate_optical_flow.py:584-600"):
+        assert needle in txt
+
+
+def test_library_exports_every_declared_symbol():
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in teeflow.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    assert L.tf_abi_version() == 1
+
+
+def test_ctypes_struct_layout_equals_c(tmp_path):
+    from tee_optical_flow_amd import _lib
+    src = tmp_path / "lay.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "teeflow.h"\nint main(){'
+                   'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(tf_params), offsetof(tf_params, nscales), offsetof(tf_params, max_batch),'
+                   ' sizeof(tf_stats), offsetof(tf_stats, iter_ms), offsetof(tf_stats, outer_iters_total)); return 0; }\n')
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    P, S = _lib.TfParams, _lib.TfStats
+    assert vals == [C.sizeof(P), P.nscales.offset, P.max_batch.offset, C.sizeof(S), S.iter_ms.offset, S.outer_iters_total.offset]
+
+
+def test_default_params_are_cv2_defaults():
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    p = _lib.TfParams()
+    assert L.tf_default_params(C.byref(p)) == 0
+    assert (p.tau, p.lambda_, p.theta, p.nscales, p.warps, p.epsilon, p.inner_iterations, p.outer_iterations, p.scale_step,
+            p.gamma, p.median_filtering, p.use_initial_flow) == (0.25, 0.15, 0.3, 5, 5, 0.01, 30, 10, 0.8, 0.0, 5, 0)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path must raise, not compute on the CPU."""
+    import torch
+    import tee_optical_flow_amd as T
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(T.OpticalFlowCalculationError, match="no HIP device|no CPU fallback"):
+        T.DenseFlow()
+    with pytest.raises(T.OpticalFlowCalculationError):
+        T.createOptFlow_DualTVL1()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tee_optical_flow_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libtvl1_oracle" not in txt, f
+
+
+def test_median_networks_proved_by_zero_one_principle(tmp_path):
+    exe = tmp_path / "vmn"
+    subprocess.check_call(["g++", "-O2", "-I", os.path.join(ROOT, "tee_optical_flow_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "csrc", "verify_median_net.cpp"), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).decode().strip() == "OK"
+
+
+def test_hip_sources_have_no_compat_layers():
+    for f in ("teeflow.hip", "teeflow_kernels.hip.h"):
+        txt = open(os.path.join(ROOT, "tee_optical_flow_amd", "csrc", f)).read()
+        for bad in ("__HIP_PLATFORM_AMD__", "cuda_runtime", "__CUDACC__", "triton"):
+            assert bad not in txt
+
+
+def test_input_validation_happens_before_any_gpu_work():
+    from tee_optical_flow_amd.dense_flow import _u8_image_stack
+    from tee_optical_flow_amd import OpticalFlowCalculationError
+    with pytest.raises(OpticalFlowCalculationError):
+        _u8_image_stack(np.zeros((4, 4), np.float32), "I0", 2)
+    with pytest.raises(OpticalFlowCalculationError):
+        _u8_image_stack(np.zeros((4, 4, 3), np.uint8), "I0", 2)
+    a = _u8_image_stack(np.zeros((8, 8), np.uint8)[::2, ::2], "I0", 2)
+    assert a.flags["C_CONTIGUOUS"]
