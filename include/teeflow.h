@@ -129,7 +129,8 @@ int tf_device_count(void);
 
 /* ---- kernel-level test hooks (dense host arrays, one image; used by tests/ to compare each kernel
  *      with the oracle bit for bit; not part of the drop-in surface) -------------------------------- */
-/* implementation knobs for experiments: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips),
+/* implementation knobs for experiments: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips, 2 = row strips
+ * with two iterations per launch), "min_rows_work" (rows*pairs below which tiles are used),
  * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
  * stop reports). Results never change. */
 int tf_set_tuning(tf_handle* h, const char* name, int value);

@@ -67,7 +67,9 @@ struct tf_handle {
     // per-call accumulators
     unsigned long long iter_launches = 0;
     // tuning knobs (tf_set_tuning)
-    int iter_variant = 1;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows) when W <= 1024
+    int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
+                                 // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
+    int min_rows_work = 4096;    // rows*pairs below which the tile kernel is used (tiny launches / single-pair latency)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
 };
@@ -201,16 +203,39 @@ struct StageTotals {
     double iter_bytes = 0, total_bytes = 0;
 };
 
+// full-width strips need W <= 1024 and enough rows*pairs to fill 256 CUs; tiny launches (single-pair latency mode) keep the tiles
+bool rows_ok(const tf_handle* h, const Geom& g, int B)
+{
+    return h->iter_variant >= 1 && g.w <= 1024 && (long long)g.h * B >= h->min_rows_work;
+}
+
+void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int* RY)
+{
+    *QX = (g.w + 3) / 4; *RY = 256 / *QX;
+    long long n = (long long)g.h * B / ((long long)h->strip_blocks * *RY);
+    if (n < 2) n = 2;
+    if (n > 16) n = 16;
+    *R = *RY * (int)n;
+}
+
+// launch one two-iteration tvl1_iter step (k_iter2_rows)
+void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
+{
+    const Geom& g = A.a.g;
+    int R, QX, RY;
+    strip_shape(h, g, B, &R, &QX, &RY);
+    const int LW = QX * 4 + 4;
+    const size_t shmem = (size_t)(16 + 8 * RY * LW + 4 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
+    hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(256), shmem, s, A, R, QX, RY);
+}
+
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
 void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 {
     const Geom& g = ia.g;
-    if (h->iter_variant == 1 && g.w <= 1024) {
-        const int QX = (g.w + 3) / 4, RY = 256 / QX;
-        long long n = (long long)g.h * B / ((long long)h->strip_blocks * RY);
-        if (n < 2) n = 2;
-        if (n > 16) n = 16;
-        const int R = RY * (int)n;
+    if (rows_ok(h, g, B)) {
+        int R, QX, RY;
+        strip_shape(h, g, B, &R, &QX, &RY);
         const int LW = QX * 4 + 4;
         const size_t shmem = (size_t)(8 + 8 * RY * LW + 2 * RY * QX) * sizeof(float);
         hipLaunchKernelGGL(k_iter_rows, dim3((g.h + R - 1) / R, 1, B), dim3(256), shmem, s, ia, R, QX, RY);
@@ -245,6 +270,62 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
+    const bool two = h->iter_variant == 2 && rows_ok(h, g, B) && (inner % 2 == 0);
+    if (two) {
+        // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
+        int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
+        bool stop = false;
+        const unsigned seq0 = h->launch_seq;
+        unsigned checked = seq0;
+        for (int it = 0; it <= total && !stop; it += 2) {
+            if (it < total && it % inner == 0 && P.median_filtering > 1) {
+                ma.it = it; ma.utog = utog;
+                if (P.median_filtering == 5) hipLaunchKernelGGL(k_median2<5>, gm, dim3(256), 0, s, ma, total);
+                else hipLaunchKernelGGL(k_median2<3>, gm, dim3(256), 0, s, ma, total);
+                ++utog;
+            }
+            const unsigned q = h->launch_seq++;
+            h->slots_host[q % SLOT_RING] = -1;
+            Iter2Args A2;
+            A2.a = ia;
+            A2.a.host_slot = h->slots_dev + q % SLOT_RING;
+            A2.a.it = it; A2.a.utog = utog; A2.a.ptog = ptog; A2.a.pzero = (wi == 0 && it == 0) ? 1 : 0;
+            A2.utog_prev = utog_prev; A2.ptog_prev = ptog_prev; A2.pzero_prev = pzero_prev; A2.total = total;
+            if (h->profile) {
+                if (h->prof_used == h->prof_pool.size()) {
+                    ProfEv pe;
+                    HIPC(h, hipEventCreate(&pe.a)); HIPC(h, hipEventCreate(&pe.b));
+                    h->prof_pool.push_back(pe);
+                }
+                ProfEv& pe = h->prof_pool[h->prof_used++];
+                HIPC(h, hipEventRecord(pe.a, s));
+                launch_iter2(h, A2, B, s);
+                HIPC(h, hipEventRecord(pe.b, s));
+            } else {
+                launch_iter2(h, A2, B, s);
+            }
+            ++h->iter_launches;
+            utog_prev = utog; ptog_prev = ptog; pzero_prev = A2.a.pzero;
+            ++utog; ++ptog;
+            while (checked <= q) {
+                int v = h->slots_host[checked % SLOT_RING];
+                if (v < 0) {
+                    if (q - checked < (unsigned)h->lag) break;
+                    const double t0 = now_ms();
+                    while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
+                        if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "tvl1_iter launch %u never reported (GPU hang?)", checked);
+                        if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
+                            return fail(h, TF_ERR_HIP, "stream drained but launch %u did not report", checked);
+                    }
+                }
+                ++checked;
+                if (v == 0) { stop = true; break; }
+            }
+        }
+        hipLaunchKernelGGL(k_stage_end2, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
+                           total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
+        return TF_OK;
+    }
     int utog = 0, ptog = 0;
     bool stop = false;
     const unsigned seq0 = h->launch_seq;
@@ -500,6 +581,8 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter2_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute");
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     {
         void* hp = nullptr; void* dp = nullptr;
@@ -605,6 +688,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     if (n == "iter_variant") h->iter_variant = value;
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
     else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
+    else if (n == "min_rows_work") h->min_rows_work = value;
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
 }
@@ -782,9 +866,20 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     }
     ia.ctl = ctl; ia.err = errs; ia.errstride = nsteps + 1; ia.thr_q = -1.0; ia.g = g; ia.host_slot = nullptr; ia.B = 1;
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
-    for (int it = 0; it < nsteps; ++it) {
-        ia.it = it; ia.utog = it; ia.ptog = it; ia.pzero = (p_is_zero && it == 0) ? 1 : 0;
-        launch_iter(h, ia, 1, h->stream);
+    const bool two = h->iter_variant == 2 && rows_ok(h, g, 1) && nsteps % 2 == 0;
+    int launches = 0;
+    if (two) {
+        for (int it = 0; it < nsteps; it += 2, ++launches) {
+            Iter2Args A2;
+            A2.a = ia; A2.a.it = it; A2.a.utog = launches; A2.a.ptog = launches; A2.a.pzero = (p_is_zero && it == 0) ? 1 : 0;
+            A2.utog_prev = A2.ptog_prev = A2.pzero_prev = 0; A2.total = nsteps;
+            launch_iter2(h, A2, 1, h->stream);
+        }
+    } else {
+        for (int it = 0; it < nsteps; ++it, ++launches) {
+            ia.it = it; ia.utog = it; ia.ptog = it; ia.pzero = (p_is_zero && it == 0) ? 1 : 0;
+            launch_iter(h, ia, 1, h->stream);
+        }
     }
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && err_q && nsteps > 0) {
@@ -793,7 +888,7 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     }
     (void)hipFree(ctl); (void)hipFree(errs);
     if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_iter: %s", hipGetErrorString(e));
-    const int cur = nsteps & 1;
+    const int cur = launches & 1;
     for (int k = 0; k < 6; ++k)
         if ((rc = dbg_down(h, hostp[k], s[2 * k + cur].p, g))) return rc;
     return TF_OK;

@@ -603,6 +603,353 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// tvl1_iter x2: TWO inner iterations per launch inside the row march (time skewing).  The strip's rows flow
+// through a 3-stage pipeline, one row group per step:
+//     stage 1 (group s)   : load row, u1 = U(u0, p0)                         [iteration `it`]
+//     stage 2 (group s-1) : p1 = P(p0, u1) ; u2 = U(u1, p1)                   [`it` dual, `it+1` primal]
+//     stage 3 (group s-2) : p2 = P(p1, u2) ; store u2, p2                     [`it+1` dual]
+// so the 9 input planes are read once and the 6 state planes written once per TWO iterations (30 B/px per
+// iteration instead of 60).  Extra work: one halo row above and two below each strip.
+//
+// Stopping stays exact.  A launch covers iterations (it, it+1); both error sums are accumulated.  If a pair
+// met the threshold already at `it`, the launch overshot by one iteration; the state it read is still
+// intact in the other ping-pong half, so the NEXT launch re-runs that pair in REPLAY mode: iteration `it`
+// alone, from the previous launch's source buffers into its destination buffers (no error accumulation).
+//   active_at(j)  = j == 0 || (err[j-2] > thr && err[j-1] > thr)           (j even; slots are zeroed per stage)
+//   NORMAL  at it : it < total && active_at(it)
+//   REPLAY  at it : it >= 2 && active_at(it-2) && !(err[it-2] > thr)
+// ---------------------------------------------------------------------------------------------
+#define M_EXIT 0
+#define M_NORMAL 1
+#define M_REPLAY 2
+
+__device__ __forceinline__ int pair_mode2(const u64* e, int it, int total, double thr)
+{
+    const bool a1 = it >= 1 ? (double)e[it - 1] > thr : true;
+    const bool a2 = it >= 2 ? (double)e[it - 2] > thr : true;
+    if (it < total && (it == 0 || (a2 && a1))) return M_NORMAL;
+    if (it >= 2 && !a2) {
+        const int j = it - 2;
+        const bool act = j == 0 || ((double)e[j - 2] > thr && (double)e[j - 1] > thr);
+        if (act) return M_REPLAY;
+    }
+    return M_EXIT;
+}
+
+struct Iter2Args {
+    IterArgs a;                           // a.it = first iteration of the launch (even), a.utog/ptog/pzero for it
+    int utog_prev, ptog_prev, pzero_prev; // the same three for the previous launch (used by REPLAY blocks)
+    int total;                            // inner*outer
+};
+
+__device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
+{
+    const IterArgs& a = A.a;
+    if (a.host_slot && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
+        int c = 0;
+        for (int b2 = threadIdx.x; b2 < a.B; b2 += 64)
+            c += pair_mode2(a.err + (size_t)b2 * a.errstride, a.it, A.total, a.thr_q) != M_EXIT ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (threadIdx.x == 0) __hip_atomic_store(a.host_slot, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+#define UNPACK4(dst, v) { dst[0] = (v).x; dst[1] = (v).y; dst[2] = (v).z; dst[3] = (v).w; }
+#define PACK4(a) make_float4((a)[0], (a)[1], (a)[2], (a)[3])
+
+__global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int QX, int RY)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const IterArgs& a = A.a;
+    const int LW = QX * 4 + 4;
+    u64* sred = reinterpret_cast<u64*>(smem);      // 8 x u64 = 64 B
+    float* U1a = smem + 16;                        // [2][RY][LW]  u1 (first iterate) plane 1 / 2
+    float* U1b = U1a + 2 * RY * LW;
+    float* U2a = U1b + 2 * RY * LW;                // [2][RY][LW]  u2 (second iterate)
+    float* U2b = U2a + 2 * RY * LW;
+    float* A12 = U2b + 2 * RY * LW;                // [RY+1][LW]   rolling rows of p0_12 / p0_22
+    float* A22 = A12 + (RY + 1) * LW;
+    float* B12 = A22 + (RY + 1) * LW;              // [RY+1][LW]   rolling rows of p1_12 / p1_22
+    float* B22 = B12 + (RY + 1) * LW;
+    float* A11w = B22 + (RY + 1) * LW;             // [RY][QX]     last element of each quad of p0_11 / p0_21
+    float* A21w = A11w + RY * QX;
+    float* B11w = A21w + RY * QX;                  //              ... of p1_11 / p1_21
+    float* B21w = B11w + RY * QX;
+
+    publish_active_count2(A);
+    const int b = blockIdx.z;
+    u64* errb = a.err + (size_t)b * a.errstride;
+    const int mode = pair_mode2(errb, a.it, A.total, a.thr_q);   // block-uniform
+    if (mode == M_EXIT) return;
+    const bool replay = mode == M_REPLAY;
+    const PairCtl c = a.ctl[b];
+    const int utog = replay ? A.utog_prev : a.utog, ptog = replay ? A.ptog_prev : a.ptog;
+    const bool pzero = (replay ? A.pzero_prev : a.pzero) != 0;
+    const int uc = (c.ubase ^ utog) & 1, pc = (c.pbase ^ ptog) & 1;
+    const int tid = threadIdx.x;
+    const int ty = tid / QX, tx = tid - ty * QX;
+    const bool lane_on = ty < RY;
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    const int x = tx * 4;
+    const int y0 = blockIdx.x * R;
+    const int n = R / RY;
+    const int ngroups = n + 2 + (RY == 1 ? 1 : 0);
+    const size_t po = (size_t)b * a.g.splane;
+    const int RB = RY + 1;
+
+    const float* __restrict__ gu1 = a.sb.u1[uc] + po;
+    const float* __restrict__ gu2 = a.sb.u2[uc] + po;
+    const float* __restrict__ g11 = a.sb.p11[pc] + po;
+    const float* __restrict__ g12 = a.sb.p12[pc] + po;
+    const float* __restrict__ g21 = a.sb.p21[pc] + po;
+    const float* __restrict__ g22 = a.sb.p22[pc] + po;
+    const float* __restrict__ gwx = a.wx + po;
+    const float* __restrict__ gwy = a.wy + po;
+    const float* __restrict__ grh = a.rho + po;
+    float* __restrict__ ou1 = a.sb.u1[uc ^ 1] + po;
+    float* __restrict__ ou2 = a.sb.u2[uc ^ 1] + po;
+    float* __restrict__ o11 = a.sb.p11[pc ^ 1] + po;
+    float* __restrict__ o12 = a.sb.p12[pc ^ 1] + po;
+    float* __restrict__ o21 = a.sb.p21[pc ^ 1] + po;
+    float* __restrict__ o22 = a.sb.p22[pc ^ 1] + po;
+
+    // row predicates (absolute row index)
+    const int yu1_lo = y0 - 1, yu1_hi = y0 + R + 1, yp1_hi = y0 + R, yout_hi = y0 + R - 1;
+
+    // pipeline registers
+    float s1_u1[4], s1_u2[4], s1_wx[4], s1_wy[4], s1_r[4], s1_11[4], s1_12[4], s1_21[4], s1_22[4];   // stage1 -> stage2
+    float s2_u1[4], s2_u2[4], s2_11[4], s2_12[4], s2_21[4], s2_22[4];                                  // stage2 -> stage3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s1_u1[i] = s1_u2[i] = s1_wx[i] = s1_wy[i] = s1_r[i] = s1_11[i] = s1_12[i] = s1_21[i] = s1_22[i] = 0.f;
+        s2_u1[i] = s2_u2[i] = s2_11[i] = s2_12[i] = s2_21[i] = s2_22[i] = 0.f;
+    }
+    bool s1_valid = false, s2_valid = false;
+    u64 qA = 0, qB = 0;
+
+    for (int s = 0; s < ngroups + 2; ++s) {
+        // ================= stage 1: group s, iteration `it` primal =================
+        const int r1 = s * RY + ty;                       // linear row counter inside the strip's pipeline
+        const int y = y0 - RY + r1;
+        const bool v1 = lane_on && s < ngroups && y >= 0 && y < H && y >= yu1_lo && y <= yu1_hi;
+        const size_t row = (size_t)y * pitch + x;
+        float4 u1q, u2q, wxq, wyq, rq, a11, a12, a21, a22;
+        u1q = u2q = wxq = wyq = rq = a11 = a12 = a21 = a22 = make_float4(0, 0, 0, 0);
+        if (v1) {
+            u1q = ld4(gu1 + row); u2q = ld4(gu2 + row);
+            wxq = ld4(gwx + row); wyq = ld4(gwy + row); rq = ld4(grh + row);
+            if (!pzero) { a11 = ld4(g11 + row); a12 = ld4(g12 + row); a21 = ld4(g21 + row); a22 = ld4(g22 + row); }
+            st4(A12 + (r1 % RB) * LW + x, a12);
+            st4(A22 + (r1 % RB) * LW + x, a22);
+            A11w[ty * QX + tx] = a11.w;
+            A21w[ty * QX + tx] = a21.w;
+        }
+        __syncthreads();
+        float n_u1[4] = {0, 0, 0, 0}, n_u2[4] = {0, 0, 0, 0};
+        float c11[4], c12[4], c21[4], c22[4], wxv[4], wyv[4], rv[4];
+        UNPACK4(c11, a11) UNPACK4(c12, a12) UNPACK4(c21, a21) UNPACK4(c22, a22) UNPACK4(wxv, wxq) UNPACK4(wyv, wyq) UNPACK4(rv, rq)
+        if (v1) {
+            float4 up12 = make_float4(0, 0, 0, 0), up22 = up12;
+            if (y > 0) {
+                if (y - 1 >= yu1_lo) { up12 = ld4(A12 + ((r1 - 1) % RB) * LW + x); up22 = ld4(A22 + ((r1 - 1) % RB) * LW + x); }
+                else if (!pzero) { up12 = ld4(g12 + row - pitch); up22 = ld4(g22 + row - pitch); }
+            }
+            float l11 = 0.f, l21 = 0.f;
+            if (tx > 0) { l11 = A11w[ty * QX + tx - 1]; l21 = A21w[ty * QX + tx - 1]; }
+            float u1k[4], u2k[4], q12u[4], q22u[4];
+            UNPACK4(u1k, u1q) UNPACK4(u2k, u2q) UNPACK4(q12u, up12) UNPACK4(q22u, up22)
+            const bool isout = y >= y0 && y <= yout_hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tv_u_px(a.l_t, a.theta, u1k[i], u2k[i], wxv[i], wyv[i], rv[i], c11[i], i == 0 ? l11 : c11[i - 1], c12[i], q12u[i],
+                        c21[i], i == 0 ? l21 : c21[i - 1], c22[i], q22u[i], y == 0, x + i == 0, n_u1[i], n_u2[i]);
+                if (!replay && isout && x + i < W) qA += tv_err_q(n_u1[i], u1k[i], n_u2[i], u2k[i]);
+            }
+            st4(U1a + ((s & 1) * RY + ty) * LW + x, PACK4(n_u1));
+            st4(U1b + ((s & 1) * RY + ty) * LW + x, PACK4(n_u2));
+        }
+        __syncthreads();
+        // ================= stage 2: group s-1: iteration `it` dual, then `it+1` primal =================
+        const int r2 = r1 - RY;
+        const int yb = y - RY;
+        const bool v2 = s1_valid && yb <= yp1_hi;           // s1_valid already implies in-image and >= yu1_lo
+        float p1_11[4] = {0, 0, 0, 0}, p1_12[4] = {0, 0, 0, 0}, p1_21[4] = {0, 0, 0, 0}, p1_22[4] = {0, 0, 0, 0};
+        if (v2) {
+            const int bp = (s - 1) & 1;
+            const bool lastrow = yb >= H - 1;
+            float4 dn1 = make_float4(0, 0, 0, 0), dn2 = dn1;
+            if (!lastrow) {
+                const float* d1 = ty < RY - 1 ? U1a + (bp * RY + ty + 1) * LW + x : U1a + ((s & 1) * RY) * LW + x;
+                const float* d2 = ty < RY - 1 ? U1b + (bp * RY + ty + 1) * LW + x : U1b + ((s & 1) * RY) * LW + x;
+                dn1 = ld4(d1); dn2 = ld4(d2);
+            }
+            float rr1 = 0.f, rr2 = 0.f;
+            if (x + 4 < W) { rr1 = U1a[(bp * RY + ty) * LW + x + 4]; rr2 = U1b[(bp * RY + ty) * LW + x + 4]; }
+            float dv1[4], dv2[4];
+            UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xi = x + i;
+                const float e1 = i < 3 ? s1_u1[i + 1] : rr1, e2 = i < 3 ? s1_u2[i + 1] : rr2;
+                const float u1x = xi < W - 1 ? e1 - s1_u1[i] : 0.f;
+                const float u2x = xi < W - 1 ? e2 - s1_u2[i] : 0.f;
+                const float u1y = !lastrow ? dv1[i] - s1_u1[i] : 0.f;
+                const float u2y = !lastrow ? dv2[i] - s1_u2[i] : 0.f;
+                tv_p_px(a.taut, u1x, u1y, s1_11[i], s1_12[i], p1_11[i], p1_12[i]);
+                tv_p_px(a.taut, u2x, u2y, s1_21[i], s1_22[i], p1_21[i], p1_22[i]);
+            }
+            if (replay) {
+                if (yb >= y0 && yb <= yout_hi) {
+                    const size_t prow = (size_t)yb * pitch + x;
+                    st4(ou1 + prow, PACK4(s1_u1)); st4(ou2 + prow, PACK4(s1_u2));
+                    st4(o11 + prow, PACK4(p1_11)); st4(o12 + prow, PACK4(p1_12));
+                    st4(o21 + prow, PACK4(p1_21)); st4(o22 + prow, PACK4(p1_22));
+                }
+            } else {
+                st4(B12 + (((r2 % RB) + RB) % RB) * LW + x, PACK4(p1_12));
+                st4(B22 + (((r2 % RB) + RB) % RB) * LW + x, PACK4(p1_22));
+                B11w[ty * QX + tx] = p1_11[3];
+                B21w[ty * QX + tx] = p1_21[3];
+            }
+        }
+        bool v2u = false;
+        float m_u1[4] = {0, 0, 0, 0}, m_u2[4] = {0, 0, 0, 0};
+        if (!replay) {
+            __syncthreads();
+            v2u = v2 && yb >= y0;                           // rows y0 .. y0+R get the second primal update
+            if (v2u) {
+                float4 up12 = make_float4(0, 0, 0, 0), up22 = up12;
+                if (yb > 0) {
+                    const int ri = (((r2 - 1) % RB) + RB) % RB;
+                    up12 = ld4(B12 + ri * LW + x); up22 = ld4(B22 + ri * LW + x);
+                }
+                float l11 = 0.f, l21 = 0.f;
+                if (tx > 0) { l11 = B11w[ty * QX + tx - 1]; l21 = B21w[ty * QX + tx - 1]; }
+                float q12u[4], q22u[4];
+                UNPACK4(q12u, up12) UNPACK4(q22u, up22)
+                const bool isout = yb <= yout_hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    tv_u_px(a.l_t, a.theta, s1_u1[i], s1_u2[i], s1_wx[i], s1_wy[i], s1_r[i], p1_11[i], i == 0 ? l11 : p1_11[i - 1],
+                            p1_12[i], q12u[i], p1_21[i], i == 0 ? l21 : p1_21[i - 1], p1_22[i], q22u[i], yb == 0, x + i == 0,
+                            m_u1[i], m_u2[i]);
+                    if (isout && x + i < W) qB += tv_err_q(m_u1[i], s1_u1[i], m_u2[i], s1_u2[i]);
+                }
+                st4(U2a + (((s - 1) & 1) * RY + ty) * LW + x, PACK4(m_u1));
+                st4(U2b + (((s - 1) & 1) * RY + ty) * LW + x, PACK4(m_u2));
+            }
+            __syncthreads();
+            // ================= stage 3: group s-2: iteration `it+1` dual, store =================
+            const int yc = y - 2 * RY;
+            if (s2_valid && yc <= yout_hi) {
+                const int bq = s & 1;                       // (s-2)&1
+                const bool lastrow = yc >= H - 1;
+                float4 dn1 = make_float4(0, 0, 0, 0), dn2 = dn1;
+                if (!lastrow) {
+                    const float* d1 = ty < RY - 1 ? U2a + (bq * RY + ty + 1) * LW + x : U2a + ((bq ^ 1) * RY) * LW + x;
+                    const float* d2 = ty < RY - 1 ? U2b + (bq * RY + ty + 1) * LW + x : U2b + ((bq ^ 1) * RY) * LW + x;
+                    dn1 = ld4(d1); dn2 = ld4(d2);
+                }
+                float rr1 = 0.f, rr2 = 0.f;
+                if (x + 4 < W) { rr1 = U2a[(bq * RY + ty) * LW + x + 4]; rr2 = U2b[(bq * RY + ty) * LW + x + 4]; }
+                float dv1[4], dv2[4], r11[4], r12[4], r21[4], r22[4];
+                UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int xi = x + i;
+                    const float e1 = i < 3 ? s2_u1[i + 1] : rr1, e2 = i < 3 ? s2_u2[i + 1] : rr2;
+                    const float u1x = xi < W - 1 ? e1 - s2_u1[i] : 0.f;
+                    const float u2x = xi < W - 1 ? e2 - s2_u2[i] : 0.f;
+                    const float u1y = !lastrow ? dv1[i] - s2_u1[i] : 0.f;
+                    const float u2y = !lastrow ? dv2[i] - s2_u2[i] : 0.f;
+                    tv_p_px(a.taut, u1x, u1y, s2_11[i], s2_12[i], r11[i], r12[i]);
+                    tv_p_px(a.taut, u2x, u2y, s2_21[i], s2_22[i], r21[i], r22[i]);
+                }
+                const size_t prow = (size_t)yc * pitch + x;
+                st4(ou1 + prow, PACK4(s2_u1)); st4(ou2 + prow, PACK4(s2_u2));
+                st4(o11 + prow, PACK4(r11)); st4(o12 + prow, PACK4(r12));
+                st4(o21 + prow, PACK4(r21)); st4(o22 + prow, PACK4(r22));
+            }
+        }
+        // ================= rotate the pipeline registers =================
+        s2_valid = v2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s2_u1[i] = m_u1[i]; s2_u2[i] = m_u2[i];
+            s2_11[i] = p1_11[i]; s2_12[i] = p1_12[i]; s2_21[i] = p1_21[i]; s2_22[i] = p1_22[i];
+            s1_u1[i] = n_u1[i]; s1_u2[i] = n_u2[i]; s1_wx[i] = wxv[i]; s1_wy[i] = wyv[i]; s1_r[i] = rv[i];
+            s1_11[i] = c11[i]; s1_12[i] = c12[i]; s1_21[i] = c21[i]; s1_22[i] = c22[i];
+        }
+        s1_valid = v1;
+    }
+    if (!replay) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { qA += __shfl_down(qA, off, 64); qB += __shfl_down(qB, off, 64); }
+        __syncthreads();
+        if ((tid & 63) == 0) { sred[tid >> 6] = qA; sred[4 + (tid >> 6)] = qB; }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&errb[a.it], sred[0] + sred[1] + sred[2] + sred[3]);
+            atomicAdd(&errb[a.it + 1], sred[4] + sred[5] + sred[6] + sred[7]);
+        }
+    }
+}
+
+// median for the two-iterations-per-launch schedule: a pair takes part iff it is in NORMAL mode at `it`
+template <int KS>
+__global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
+{
+    constexpr int R = KS / 2, TWm = 64, THm = 16, LW = TWm + 2 * R, LH = THm + 2 * R;
+    __shared__ float t[LH][LW];
+    const int b = blockIdx.z >> 1, plane = blockIdx.z & 1;
+    if (pair_mode2(a.err + (size_t)b * a.errstride, a.it, total, a.thr_q) != M_NORMAL) return;
+    const int uc = (a.ctl[b].ubase ^ a.utog) & 1;
+    const size_t po = (size_t)b * a.g.splane;
+    const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
+    float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
+    const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        t[ly][lx] = src[(size_t)clampi(y0 - R + ly, 0, H - 1) * pitch + clampi(x0 - R + lx, 0, W - 1)];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ly = (threadIdx.x >> 6) + 4 * r, y = y0 + ly;
+        if (x < W && y < H) {
+            float p[KS * KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int i = 0; i < KS; ++i) p[j * KS + i] = t[ly + j][lx + i];
+            dst[(size_t)y * pitch + x] = (KS == 5) ? tf_median25(p) : tf_median9(p);
+        }
+    }
+}
+
+// stage end for the two-iterations-per-launch schedule: a pair took part in ceil(n_it/2) launches
+__global__ void k_stage_end2(const u64* __restrict__ err, int errstride, PairCtl* ctl, int* iters, int B,
+                             int total, int inner, int median_on, double thr_q, int level, int warp, int nlev, int warps)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const u64* e = err + (size_t)b * errstride;
+    int n_it = total;
+    for (int j = 0; j < total; ++j)
+        if (!((double)e[j] > thr_q)) { n_it = j + 1; break; }
+    const int n_out = n_it > 0 ? (n_it - 1) / inner + 1 : 0;
+    const int launches = (n_it + 1) / 2;
+    PairCtl c = ctl[b];
+    c.ubase = (c.ubase + launches + (median_on ? n_out : 0)) & 1;
+    c.pbase = (c.pbase + launches) & 1;
+    ctl[b] = c;
+    int* o = iters + (((size_t)b * nlev + level) * warps + warp) * 2;
+    o[0] = n_it; o[1] = n_out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // control kernels (a few threads; they keep the stop/continue decisions on the device)
 // ---------------------------------------------------------------------------------------------
 // end of one (level, warp) stage: executed iteration counts -> stats; advance the ping-pong bases

@@ -84,12 +84,25 @@ def test_median_bit_exact(engine, oracle, shape, ksize):
     assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (210, 210), (15, 60), (16, 61), (31, 121), (512, 512)])
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (210, 210), (15, 60), (16, 61), (31, 121), (512, 512), (3, 1021)])
 @pytest.mark.parametrize("pzero", [0, 1])
-def test_iterate_bit_exact(engine, oracle, shape, pzero):
-    """k steps of the fused tvl1_iter kernel == k oracle iterations (state AND exact error sums)."""
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
+    """k steps of the fused tvl1_iter kernel == k oracle iterations (state AND exact error sums), for all three
+    kernel forms: 64x16 tiles, full-width row strips, row strips with two iterations per launch."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
+    engine.set_tuning("iter_variant", variant)
+    engine.set_tuning("min_rows_work", 0)        # force the strip kernels even for this single small image
+    try:
+        _iterate_case(engine, oracle, L, shape, pzero)
+    finally:
+        engine.set_tuning("iter_variant", 2)
+        engine.set_tuning("min_rows_work", 4096)
+
+
+def _iterate_case(engine, oracle, L, shape, pzero):
+    from tee_optical_flow_amd import _lib
     h, w = shape
     rng = np.random.default_rng(7)
     I0, I1 = _rng_img(8, h, w), _rng_img(9, h, w)
@@ -107,7 +120,7 @@ def test_iterate_bit_exact(engine, oracle, shape, pzero):
         p = [np.zeros((h, w), np.float32) for _ in range(4)]
     else:
         p = [rng.uniform(-0.5, 0.5, (h, w)).astype(np.float32) for _ in range(4)]
-    nsteps = 5
+    nsteps = 6
     ref = oracle.iterate(wx, wy, grad, rho, u1, u2, *p, nsteps)
     st = [a.copy() for a in (u1, u2, *p)]
     err = np.zeros(nsteps, np.uint64)

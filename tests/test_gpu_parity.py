@@ -98,6 +98,34 @@ def test_non_default_parameters_match_oracle(oracle, params):
     eng.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("params", [dict(), dict(inner_iterations=7, outer_iterations=4), dict(inner_iterations=4, outer_iterations=3, epsilon=0.002),
+                                    dict(median_filtering=1, epsilon=0.03)])
+def test_every_iteration_kernel_form_end_to_end(oracle, variant, params):
+    """The three tvl1_iter forms (tiles / row strips / two iterations per launch with per-pair REPLAY of an overshoot)
+    must give the oracle's flow and iteration counts exactly -- including stops on odd iterations, stages that hit the
+    iteration cap (tiny epsilon), odd `inner` (falls back to one iteration per launch) and a batch whose pairs stop at
+    different iterations."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs
+    I0s, I1s = speckle_pairs(range(70, 76), 72, 88)
+    eng = T.DenseFlow(**params)
+    eng.set_tuning("iter_variant", variant)
+    eng.set_tuning("min_rows_work", 0)
+    flows = eng.calc_pairs(I0s, I1s)
+    iters = eng.last_iters()
+    op = oracle.default_params(**params)
+    odd = even = 0
+    for b in range(len(I0s)):
+        ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], op, return_iters=True)
+        assert np.array_equal(iters[b], ref_it[:nl]), f"pair {b} iteration counts"
+        assert np.array_equal(flows[b], ref), f"pair {b} flow"
+        odd += int((ref_it[:nl, :, 0] % 2 == 1).sum()); even += int((ref_it[:nl, :, 0] % 2 == 0).sum())
+    if not params:
+        assert odd > 0 and even > 0    # both the REPLAY and the clean-stop path were exercised
+    eng.close()
+
+
 def test_symmetries(engine):
     """SURVEY.md 8c item 3 (behavioural KATs on the GPU path itself): transpose swaps (u,v)."""
     from tee_optical_flow_amd.synth import speckle_pair
