@@ -6,7 +6,7 @@ import os
 from .exceptions import OpticalFlowCalculationError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libteeflow_hip.so")
+LIB_PATH = os.environ.get("TEEFLOW_LIB", os.path.join(_HERE, "libteeflow_hip.so"))   # override only for A/B experiments
 
 TF_OK = 0
 PARAM_KEYS = {

@@ -225,7 +225,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
     int R, QX, RY;
     strip_shape(h, g, B, &R, &QX, &RY);
     const int LW = QX * 4 + 4;
-    const size_t shmem = (size_t)(16 + 8 * RY * LW + 4 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
+    const size_t shmem = (size_t)(16 + 8 * RY * LW + 2 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(256), shmem, s, A, R, QX, RY);
 }
 

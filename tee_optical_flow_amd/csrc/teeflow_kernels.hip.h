@@ -43,6 +43,9 @@ struct StateBufs {
 #define ERR_SCALE_F 1073741824.0f  // 2^30: per-pixel convergence term -> exact integer (oracle D1)
 #define ERR_CAP_F 4096.0f
 
+#define UNPACK4(dst, v) { dst[0] = (v).x; dst[1] = (v).y; dst[2] = (v).z; dst[3] = (v).w; }
+#define PACK4(a) make_float4((a)[0], (a)[1], (a)[2], (a)[3])
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -292,10 +295,107 @@ __device__ __forceinline__ void publish_active_count(const IterArgs& a)
     }
 }
 
+// ---- exact arithmetic helpers shared by the three tvl1_iter forms ----------------------------------------
+// All of them return the SAME bits as the plain C expressions in the oracle; they only drop work that the
+// generic lowering does for operand ranges that cannot occur here.  tests/test_gpu_kernels.py compares the
+// results with the oracle bit for bit.
+
+// oracle D2: (float)sqrt((double)a*a + (double)b*b).  a*a, b*b are exact in double, so fma(a,a,b*b) is the same
+// single rounding as the sum of the two products.  The square root is the Goldschmidt sequence hipcc emits for
+// sqrt(double) (correctly rounded), without its ldexp rescaling for x < 2^-767: x is 0 or >= 2^-298 here.
 __device__ __forceinline__ float hypot_exact(float a, float b)
 {
-    // oracle D2: (float)sqrt((double)a*a + (double)b*b), all steps correctly rounded
-    return (float)__dsqrt_rn((double)a * (double)a + (double)b * (double)b);
+    const double ad = (double)a, bd = (double)b;
+    const double x = __builtin_fma(ad, ad, bd * bd);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    g = (x == 0.0 || x == __builtin_inf()) ? x : g;
+    return (float)g;
+}
+
+// rint(x) for 0 <= x < 2^43 as uint64 (x = min(t,4096)*2^30): split at 2^32, both halves exact
+__device__ __forceinline__ u64 rint_u64(float x)
+{
+    const float v = __builtin_rintf(x);
+    const float hi = __builtin_floorf(v * 0x1p-32f);
+    const float lo = __builtin_fmaf(hi, -0x1p32f, v);
+    return ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo;
+}
+
+// estimateV + divergence + estimateU for the 4 pixels of one quad.  `ytop` is uniform per row; only the first pixel of
+// the first quad (x == 0) has no left neighbour.
+struct QuadU {
+    float u1k[4], u2k[4], wx[4], wy[4], r[4];       // current flow and warp constants
+    float p11[4], p12[4], p21[4], p22[4];           // dual variable at the pixel
+    float p12u[4], p22u[4];                         // ... one row up
+    float l11, l21;                                 // ... p11/p21 of the pixel left of the quad
+};
+
+__device__ __forceinline__ void tv_u_quad(float l_t, float theta, const QuadU& q, bool ytop, bool x0, float* u1n, float* u2n)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // estimateV, branch-free: the three cases of the thresholding step become selects (the quotient is computed
+        // in every lane and discarded where it does not apply; straight-line code lets the 4 pixels interleave)
+        const float Ix2 = q.wx[i] * q.wx[i], Iy2 = q.wy[i] * q.wy[i];
+        const float grad = Ix2 + Iy2;
+        const float rho = q.r[i] + (q.wx[i] * q.u1k[i] + q.wy[i] * q.u2k[i]);
+        const float lg = l_t * grad;
+        const bool c1 = rho < -lg, c2 = rho > lg, c3 = grad > FLT_EPSILON;
+        const float fi = -rho / grad;
+        const float k = c1 ? l_t : (c2 ? -l_t : fi);
+        const bool any = c1 || c2 || c3;
+        const float d1 = any ? k * q.wx[i] : 0.f, d2 = any ? k * q.wy[i] : 0.f;
+        const float v1 = q.u1k[i] + d1, v2 = q.u2k[i] + d2;
+        const float p11l = i == 0 ? q.l11 : q.p11[i - 1], p21l = i == 0 ? q.l21 : q.p21[i - 1];
+        // divergence: backward differences with upstream's first-row / first-column forms
+        float div1, div2;
+        if (!ytop) {
+            div1 = (q.p11[i] - p11l) + (q.p12[i] - q.p12u[i]); div2 = (q.p21[i] - p21l) + (q.p22[i] - q.p22u[i]);
+            if (i == 0) {
+                const float b1 = (q.p11[i] + q.p12[i]) - q.p12u[i], b2 = (q.p21[i] + q.p22[i]) - q.p22u[i];
+                div1 = x0 ? b1 : div1; div2 = x0 ? b2 : div2;
+            }
+        } else {
+            div1 = (q.p11[i] - p11l) + q.p12[i]; div2 = (q.p21[i] - p21l) + q.p22[i];
+            if (i == 0) {
+                const float b1 = q.p11[i] + q.p12[i], b2 = q.p21[i] + q.p22[i];
+                div1 = x0 ? b1 : div1; div2 = x0 ? b2 : div2;
+            }
+        }
+        u1n[i] = v1 + theta * div1;
+        u2n[i] = v2 + theta * div2;
+    }
+}
+
+__device__ __forceinline__ u64 tv_err_q(float u1n, float u1k, float u2n, float u2k)
+{
+    const float e1 = u1n - u1k, e2 = u2n - u2k;
+    const float t = e1 * e1 + e2 * e2;
+    return rint_u64(fminf(t, ERR_CAP_F) * ERR_SCALE_F);
+}
+
+// estimateDualVariables for the 4 pixels of a quad, both flow components.  (A hand-rolled division sharing the
+// reciprocal between the two quotients by the same 1 + taut*|grad u| was bit-exact but 15 % SLOWER: the wave vote that
+// guards its operand range splits the basic block and stops the 16 divisions from interleaving.)
+__device__ __forceinline__ void tv_p_quad(float taut, const float* u1x, const float* u1y, const float* u2x, const float* u2y,
+                                          const float* p11, const float* p12, const float* p21, const float* p22,
+                                          float* o11, float* o12, float* o21, float* o22)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float ng1 = 1.0f + taut * hypot_exact(u1x[i], u1y[i]);
+        const float ng2 = 1.0f + taut * hypot_exact(u2x[i], u2y[i]);
+        o11[i] = (p11[i] + taut * u1x[i]) / ng1; o12[i] = (p12[i] + taut * u1y[i]) / ng1;
+        o21[i] = (p21[i] + taut * u2x[i]) / ng2; o22[i] = (p22[i] + taut * u2y[i]) / ng2;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_iter(IterArgs a)
@@ -330,77 +430,34 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
             if (y > 0) { up12 = ld4(a.sb.p12[pc] + row - pitch); up22 = ld4(a.sb.p22[pc] + row - pitch); }
             if (x > 0) { l11 = a.sb.p11[pc][row - 1]; l21 = a.sb.p21[pc][row - 1]; }
         }
-        const float u1k[4] = {u1q.x, u1q.y, u1q.z, u1q.w}, u2k[4] = {u2q.x, u2q.y, u2q.z, u2q.w};
-        const float wxv[4] = {wxq.x, wxq.y, wxq.z, wxq.w}, wyv[4] = {wyq.x, wyq.y, wyq.z, wyq.w};
-        const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
-        const float q12u[4] = {up12.x, up12.y, up12.z, up12.w}, q22u[4] = {up22.x, up22.y, up22.z, up22.w};
-        p11c[0] = a11.x; p11c[1] = a11.y; p11c[2] = a11.z; p11c[3] = a11.w;
-        p12c[0] = a12.x; p12c[1] = a12.y; p12c[2] = a12.z; p12c[3] = a12.w;
-        p21c[0] = a21.x; p21c[1] = a21.y; p21c[2] = a21.z; p21c[3] = a21.w;
-        p22c[0] = a22.x; p22c[1] = a22.y; p22c[2] = a22.z; p22c[3] = a22.w;
+        QuadU qu;
+        UNPACK4(qu.u1k, u1q) UNPACK4(qu.u2k, u2q) UNPACK4(qu.wx, wxq) UNPACK4(qu.wy, wyq) UNPACK4(qu.r, rq)
+        UNPACK4(qu.p11, a11) UNPACK4(qu.p12, a12) UNPACK4(qu.p21, a21) UNPACK4(qu.p22, a22)
+        UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
+        qu.l11 = l11; qu.l21 = l21;
+        UNPACK4(p11c, a11) UNPACK4(p12c, a12) UNPACK4(p21c, a21) UNPACK4(p22c, a22)
+        tv_u_quad(a.l_t, a.theta, qu, y == 0, x == 0, u1n, u2n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int xi = x + i;
-            // estimateV
-            const float Ix2 = wxv[i] * wxv[i], Iy2 = wyv[i] * wyv[i];
-            const float grad = Ix2 + Iy2;
-            const float rho = rv[i] + (wxv[i] * u1k[i] + wyv[i] * u2k[i]);
-            const float lg = a.l_t * grad;
-            float d1 = 0.f, d2 = 0.f;
-            if (rho < -lg) { d1 = a.l_t * wxv[i]; d2 = a.l_t * wyv[i]; }
-            else if (rho > lg) { d1 = -a.l_t * wxv[i]; d2 = -a.l_t * wyv[i]; }
-            else if (grad > FLT_EPSILON) { const float fi = -rho / grad; d1 = fi * wxv[i]; d2 = fi * wyv[i]; }
-            const float v1 = u1k[i] + d1, v2 = u2k[i] + d2;
-            // divergence (backward differences; upstream's first-row / first-column forms)
-            const float p11l = i == 0 ? l11 : p11c[i - 1];
-            const float p21l = i == 0 ? l21 : p21c[i - 1];
-            float div1, div2;
-            if (y > 0 && xi > 0) {
-                div1 = (p11c[i] - p11l) + (p12c[i] - q12u[i]);
-                div2 = (p21c[i] - p21l) + (p22c[i] - q22u[i]);
-            } else if (y == 0 && xi > 0) {
-                div1 = (p11c[i] - p11l) + p12c[i];
-                div2 = (p21c[i] - p21l) + p22c[i];
-            } else if (xi == 0 && y > 0) {
-                div1 = (p11c[i] + p12c[i]) - q12u[i];
-                div2 = (p21c[i] + p22c[i]) - q22u[i];
-            } else {
-                div1 = p11c[i] + p12c[i];
-                div2 = p21c[i] + p22c[i];
-            }
-            // estimateU
-            u1n[i] = v1 + a.theta * div1;
-            u2n[i] = v2 + a.theta * div2;
-            if (outr && xi < W) {
-                const float e1 = u1n[i] - u1k[i], e2 = u2n[i] - u2k[i];
-                const float t = e1 * e1 + e2 * e2;
-                q += (u64)__float2ll_rn(fminf(t, ERR_CAP_F) * ERR_SCALE_F);
-            }
-        }
+        for (int i = 0; i < 4; ++i)
+            if (outr && x + i < W) q += tv_err_q(u1n[i], qu.u1k[i], u2n[i], qu.u2k[i]);
         st4(&su1[ty][tx * 4], make_float4(u1n[0], u1n[1], u1n[2], u1n[3]));
         st4(&su2[ty][tx * 4], make_float4(u2n[0], u2n[1], u2n[2], u2n[3]));
     }
     __syncthreads();
     if (outr) {
-        float o11[4], o12[4], o21[4], o22[4];
+        float o11[4], o12[4], o21[4], o22[4], u1x[4], u1y[4], u2x[4], u2y[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int xi = x + i;
             // forwardGradient of u' (0 in the last column / row)
             const float r1 = i < 3 ? u1n[i + 1] : su1[ty][tx * 4 + 4];
             const float r2 = i < 3 ? u2n[i + 1] : su2[ty][tx * 4 + 4];
-            const float u1x = xi < W - 1 ? r1 - u1n[i] : 0.f;
-            const float u2x = xi < W - 1 ? r2 - u2n[i] : 0.f;
-            const float u1y = y < H - 1 ? su1[ty + 1][tx * 4 + i] - u1n[i] : 0.f;
-            const float u2y = y < H - 1 ? su2[ty + 1][tx * 4 + i] - u2n[i] : 0.f;
-            // estimateDualVariables
-            const float ng1 = 1.0f + a.taut * hypot_exact(u1x, u1y);
-            const float ng2 = 1.0f + a.taut * hypot_exact(u2x, u2y);
-            o11[i] = (p11c[i] + a.taut * u1x) / ng1;
-            o12[i] = (p12c[i] + a.taut * u1y) / ng1;
-            o21[i] = (p21c[i] + a.taut * u2x) / ng2;
-            o22[i] = (p22c[i] + a.taut * u2y) / ng2;
+            u1x[i] = xi < W - 1 ? r1 - u1n[i] : 0.f;
+            u2x[i] = xi < W - 1 ? r2 - u2n[i] : 0.f;
+            u1y[i] = y < H - 1 ? su1[ty + 1][tx * 4 + i] - u1n[i] : 0.f;
+            u2y[i] = y < H - 1 ? su2[ty + 1][tx * 4 + i] - u2n[i] : 0.f;
         }
+        tv_p_quad(a.taut, u1x, u1y, u2x, u2y, p11c, p12c, p21c, p22c, o11, o12, o21, o22);
         st4(a.sb.u1[uc ^ 1] + row, make_float4(u1n[0], u1n[1], u1n[2], u1n[3]));
         st4(a.sb.u2[uc ^ 1] + row, make_float4(u2n[0], u2n[1], u2n[2], u2n[3]));
         st4(a.sb.p11[pc ^ 1] + row, make_float4(o11[0], o11[1], o11[2], o11[3]));
@@ -429,42 +486,6 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
 // quad to the left, u' of the quad to the right and of the row below) goes through LDS; the dual
 // update of a row is deferred by one step until the u' row below it exists.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tv_u_px(float l_t, float theta, float u1k, float u2k, float wx, float wy, float r,
-                                        float p11, float p11l, float p12, float p12u, float p21, float p21l, float p22,
-                                        float p22u, bool ytop, bool xleft, float& u1n, float& u2n)
-{
-    const float Ix2 = wx * wx, Iy2 = wy * wy;
-    const float grad = Ix2 + Iy2;
-    const float rho = r + (wx * u1k + wy * u2k);
-    const float lg = l_t * grad;
-    float d1 = 0.f, d2 = 0.f;
-    if (rho < -lg) { d1 = l_t * wx; d2 = l_t * wy; }
-    else if (rho > lg) { d1 = -l_t * wx; d2 = -l_t * wy; }
-    else if (grad > FLT_EPSILON) { const float fi = -rho / grad; d1 = fi * wx; d2 = fi * wy; }
-    const float v1 = u1k + d1, v2 = u2k + d2;
-    float div1, div2;
-    if (!ytop && !xleft) { div1 = (p11 - p11l) + (p12 - p12u); div2 = (p21 - p21l) + (p22 - p22u); }
-    else if (ytop && !xleft) { div1 = (p11 - p11l) + p12; div2 = (p21 - p21l) + p22; }
-    else if (xleft && !ytop) { div1 = (p11 + p12) - p12u; div2 = (p21 + p22) - p22u; }
-    else { div1 = p11 + p12; div2 = p21 + p22; }
-    u1n = v1 + theta * div1;
-    u2n = v2 + theta * div2;
-}
-
-__device__ __forceinline__ u64 tv_err_q(float u1n, float u1k, float u2n, float u2k)
-{
-    const float e1 = u1n - u1k, e2 = u2n - u2k;
-    const float t = e1 * e1 + e2 * e2;
-    return (u64)__float2ll_rn(fminf(t, ERR_CAP_F) * ERR_SCALE_F);
-}
-
-__device__ __forceinline__ void tv_p_px(float taut, float ux, float uy, float pa, float pb, float& oa, float& ob)
-{
-    const float ng = 1.0f + taut * hypot_exact(ux, uy);
-    oa = (pa + taut * ux) / ng;
-    ob = (pb + taut * uy) / ng;
-}
-
 __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, int RY)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -538,18 +559,15 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
             }
             float l11 = 0.f, l21 = 0.f;
             if (tx > 0) { l11 = sp11w[ty * QX + tx - 1]; l21 = sp21w[ty * QX + tx - 1]; }
-            const float u1k[4] = {u1q.x, u1q.y, u1q.z, u1q.w}, u2k[4] = {u2q.x, u2q.y, u2q.z, u2q.w};
-            const float wxv[4] = {wxq.x, wxq.y, wxq.z, wxq.w}, wyv[4] = {wyq.x, wyq.y, wyq.z, wyq.w};
-            const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
-            const float c11[4] = {a11.x, a11.y, a11.z, a11.w}, c12[4] = {a12.x, a12.y, a12.z, a12.w};
-            const float c21[4] = {a21.x, a21.y, a21.z, a21.w}, c22[4] = {a22.x, a22.y, a22.z, a22.w};
-            const float q12u[4] = {up12.x, up12.y, up12.z, up12.w}, q22u[4] = {up22.x, up22.y, up22.z, up22.w};
+            QuadU qu;
+            UNPACK4(qu.u1k, u1q) UNPACK4(qu.u2k, u2q) UNPACK4(qu.wx, wxq) UNPACK4(qu.wy, wyq) UNPACK4(qu.r, rq)
+            UNPACK4(qu.p11, a11) UNPACK4(qu.p12, a12) UNPACK4(qu.p21, a21) UNPACK4(qu.p22, a22)
+            UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
+            qu.l11 = l11; qu.l21 = l21;
+            tv_u_quad(a.l_t, a.theta, qu, y == 0, x == 0, u1n, u2n);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tv_u_px(a.l_t, a.theta, u1k[i], u2k[i], wxv[i], wyv[i], rv[i], c11[i], i == 0 ? l11 : c11[i - 1], c12[i], q12u[i],
-                        c21[i], i == 0 ? l21 : c21[i - 1], c22[i], q22u[i], y == 0, x + i == 0, u1n[i], u2n[i]);
-                if (is_out && x + i < W) q += tv_err_q(u1n[i], u1k[i], u2n[i], u2k[i]);
-            }
+            for (int i = 0; i < 4; ++i)
+                if (is_out && x + i < W) q += tv_err_q(u1n[i], qu.u1k[i], u2n[i], qu.u2k[i]);
             st4(su1 + (cur * RY + ty) * LW + x, make_float4(u1n[0], u1n[1], u1n[2], u1n[3]));
             st4(su2 + (cur * RY + ty) * LW + x, make_float4(u2n[0], u2n[1], u2n[2], u2n[3]));
             // keep this row's old p for its deferred dual update (after the previous row's update below)
@@ -565,18 +583,17 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
             float r1 = 0.f, r2 = 0.f;
             if (x + 4 < W) { r1 = su1[((cur ^ 1) * RY + ty) * LW + x + 4]; r2 = su2[((cur ^ 1) * RY + ty) * LW + x + 4]; }
             const float dv1[4] = {dn1.x, dn1.y, dn1.z, dn1.w}, dv2[4] = {dn2.x, dn2.y, dn2.z, dn2.w};
-            float o11[4], o12[4], o21[4], o22[4];
+            float o11[4], o12[4], o21[4], o22[4], u1x[4], u1y[4], u2x[4], u2y[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xi = x + i;
                 const float n1 = i < 3 ? pu1[i + 1] : r1, n2 = i < 3 ? pu2[i + 1] : r2;
-                const float u1x = xi < W - 1 ? n1 - pu1[i] : 0.f;
-                const float u2x = xi < W - 1 ? n2 - pu2[i] : 0.f;
-                const float u1y = !lastrow ? dv1[i] - pu1[i] : 0.f;
-                const float u2y = !lastrow ? dv2[i] - pu2[i] : 0.f;
-                tv_p_px(a.taut, u1x, u1y, q11[i], q12[i], o11[i], o12[i]);
-                tv_p_px(a.taut, u2x, u2y, q21[i], q22[i], o21[i], o22[i]);
+                u1x[i] = xi < W - 1 ? n1 - pu1[i] : 0.f;
+                u2x[i] = xi < W - 1 ? n2 - pu2[i] : 0.f;
+                u1y[i] = !lastrow ? dv1[i] - pu1[i] : 0.f;
+                u2y[i] = !lastrow ? dv2[i] - pu2[i] : 0.f;
             }
+            tv_p_quad(a.taut, u1x, u1y, u2x, u2y, q11, q12, q21, q22, o11, o12, o21, o22);
             const size_t prow = po + (size_t)prev_y * pitch + x;
             st4(a.sb.u1[uc ^ 1] + prow, make_float4(pu1[0], pu1[1], pu1[2], pu1[3]));
             st4(a.sb.u2[uc ^ 1] + prow, make_float4(pu2[0], pu2[1], pu2[2], pu2[3]));
@@ -655,8 +672,6 @@ __device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
     }
 }
 
-#define UNPACK4(dst, v) { dst[0] = (v).x; dst[1] = (v).y; dst[2] = (v).z; dst[3] = (v).w; }
-#define PACK4(a) make_float4((a)[0], (a)[1], (a)[2], (a)[3])
 
 __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int QX, int RY)
 {
@@ -668,9 +683,8 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
     float* U1b = U1a + 2 * RY * LW;
     float* U2a = U1b + 2 * RY * LW;                // [2][RY][LW]  u2 (second iterate)
     float* U2b = U2a + 2 * RY * LW;
-    float* A12 = U2b + 2 * RY * LW;                // [RY+1][LW]   rolling rows of p0_12 / p0_22
-    float* A22 = A12 + (RY + 1) * LW;
-    float* B12 = A22 + (RY + 1) * LW;              // [RY+1][LW]   rolling rows of p1_12 / p1_22
+    float* B12 = U2b + 2 * RY * LW;                // [RY+1][LW]   rolling rows of p1_12 / p1_22 (p0's row above is
+                                                   //              re-read from global/L2: keeps LDS at 3 blocks per CU)
     float* B22 = B12 + (RY + 1) * LW;
     float* A11w = B22 + (RY + 1) * LW;             // [RY][QX]     last element of each quad of p0_11 / p0_21
     float* A21w = A11w + RY * QX;
@@ -740,8 +754,6 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
             u1q = ld4(gu1 + row); u2q = ld4(gu2 + row);
             wxq = ld4(gwx + row); wyq = ld4(gwy + row); rq = ld4(grh + row);
             if (!pzero) { a11 = ld4(g11 + row); a12 = ld4(g12 + row); a21 = ld4(g21 + row); a22 = ld4(g22 + row); }
-            st4(A12 + (r1 % RB) * LW + x, a12);
-            st4(A22 + (r1 % RB) * LW + x, a22);
             A11w[ty * QX + tx] = a11.w;
             A21w[ty * QX + tx] = a21.w;
         }
@@ -751,21 +763,19 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
         UNPACK4(c11, a11) UNPACK4(c12, a12) UNPACK4(c21, a21) UNPACK4(c22, a22) UNPACK4(wxv, wxq) UNPACK4(wyv, wyq) UNPACK4(rv, rq)
         if (v1) {
             float4 up12 = make_float4(0, 0, 0, 0), up22 = up12;
-            if (y > 0) {
-                if (y - 1 >= yu1_lo) { up12 = ld4(A12 + ((r1 - 1) % RB) * LW + x); up22 = ld4(A22 + ((r1 - 1) % RB) * LW + x); }
-                else if (!pzero) { up12 = ld4(g12 + row - pitch); up22 = ld4(g22 + row - pitch); }
-            }
+            if (y > 0 && !pzero) { up12 = ld4(g12 + row - pitch); up22 = ld4(g22 + row - pitch); }
             float l11 = 0.f, l21 = 0.f;
             if (tx > 0) { l11 = A11w[ty * QX + tx - 1]; l21 = A21w[ty * QX + tx - 1]; }
-            float u1k[4], u2k[4], q12u[4], q22u[4];
-            UNPACK4(u1k, u1q) UNPACK4(u2k, u2q) UNPACK4(q12u, up12) UNPACK4(q22u, up22)
+            QuadU qu;
+            UNPACK4(qu.u1k, u1q) UNPACK4(qu.u2k, u2q) UNPACK4(qu.wx, wxq) UNPACK4(qu.wy, wyq) UNPACK4(qu.r, rq)
+            UNPACK4(qu.p11, a11) UNPACK4(qu.p12, a12) UNPACK4(qu.p21, a21) UNPACK4(qu.p22, a22)
+            UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
+            qu.l11 = l11; qu.l21 = l21;
             const bool isout = y >= y0 && y <= yout_hi;
+            tv_u_quad(a.l_t, a.theta, qu, y == 0, x == 0, n_u1, n_u2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tv_u_px(a.l_t, a.theta, u1k[i], u2k[i], wxv[i], wyv[i], rv[i], c11[i], i == 0 ? l11 : c11[i - 1], c12[i], q12u[i],
-                        c21[i], i == 0 ? l21 : c21[i - 1], c22[i], q22u[i], y == 0, x + i == 0, n_u1[i], n_u2[i]);
-                if (!replay && isout && x + i < W) qA += tv_err_q(n_u1[i], u1k[i], n_u2[i], u2k[i]);
-            }
+            for (int i = 0; i < 4; ++i)
+                if (!replay && isout && x + i < W) qA += tv_err_q(n_u1[i], qu.u1k[i], n_u2[i], qu.u2k[i]);
             st4(U1a + ((s & 1) * RY + ty) * LW + x, PACK4(n_u1));
             st4(U1b + ((s & 1) * RY + ty) * LW + x, PACK4(n_u2));
         }
@@ -786,19 +796,18 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
             }
             float rr1 = 0.f, rr2 = 0.f;
             if (x + 4 < W) { rr1 = U1a[(bp * RY + ty) * LW + x + 4]; rr2 = U1b[(bp * RY + ty) * LW + x + 4]; }
-            float dv1[4], dv2[4];
+            float dv1[4], dv2[4], u1x[4], u1y[4], u2x[4], u2y[4];
             UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xi = x + i;
                 const float e1 = i < 3 ? s1_u1[i + 1] : rr1, e2 = i < 3 ? s1_u2[i + 1] : rr2;
-                const float u1x = xi < W - 1 ? e1 - s1_u1[i] : 0.f;
-                const float u2x = xi < W - 1 ? e2 - s1_u2[i] : 0.f;
-                const float u1y = !lastrow ? dv1[i] - s1_u1[i] : 0.f;
-                const float u2y = !lastrow ? dv2[i] - s1_u2[i] : 0.f;
-                tv_p_px(a.taut, u1x, u1y, s1_11[i], s1_12[i], p1_11[i], p1_12[i]);
-                tv_p_px(a.taut, u2x, u2y, s1_21[i], s1_22[i], p1_21[i], p1_22[i]);
+                u1x[i] = xi < W - 1 ? e1 - s1_u1[i] : 0.f;
+                u2x[i] = xi < W - 1 ? e2 - s1_u2[i] : 0.f;
+                u1y[i] = !lastrow ? dv1[i] - s1_u1[i] : 0.f;
+                u2y[i] = !lastrow ? dv2[i] - s1_u2[i] : 0.f;
             }
+            tv_p_quad(a.taut, u1x, u1y, u2x, u2y, s1_11, s1_12, s1_21, s1_22, p1_11, p1_12, p1_21, p1_22);
             if (replay) {
                 if (yb >= y0 && yb <= yout_hi) {
                     const size_t prow = (size_t)yb * pitch + x;
@@ -826,16 +835,19 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
                 }
                 float l11 = 0.f, l21 = 0.f;
                 if (tx > 0) { l11 = B11w[ty * QX + tx - 1]; l21 = B21w[ty * QX + tx - 1]; }
-                float q12u[4], q22u[4];
-                UNPACK4(q12u, up12) UNPACK4(q22u, up22)
-                const bool isout = yb <= yout_hi;
+                QuadU qu;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    tv_u_px(a.l_t, a.theta, s1_u1[i], s1_u2[i], s1_wx[i], s1_wy[i], s1_r[i], p1_11[i], i == 0 ? l11 : p1_11[i - 1],
-                            p1_12[i], q12u[i], p1_21[i], i == 0 ? l21 : p1_21[i - 1], p1_22[i], q22u[i], yb == 0, x + i == 0,
-                            m_u1[i], m_u2[i]);
-                    if (isout && x + i < W) qB += tv_err_q(m_u1[i], s1_u1[i], m_u2[i], s1_u2[i]);
+                    qu.u1k[i] = s1_u1[i]; qu.u2k[i] = s1_u2[i]; qu.wx[i] = s1_wx[i]; qu.wy[i] = s1_wy[i]; qu.r[i] = s1_r[i];
+                    qu.p11[i] = p1_11[i]; qu.p12[i] = p1_12[i]; qu.p21[i] = p1_21[i]; qu.p22[i] = p1_22[i];
                 }
+                UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
+                qu.l11 = l11; qu.l21 = l21;
+                const bool isout = yb <= yout_hi;
+                tv_u_quad(a.l_t, a.theta, qu, yb == 0, x == 0, m_u1, m_u2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (isout && x + i < W) qB += tv_err_q(m_u1[i], s1_u1[i], m_u2[i], s1_u2[i]);
                 st4(U2a + (((s - 1) & 1) * RY + ty) * LW + x, PACK4(m_u1));
                 st4(U2b + (((s - 1) & 1) * RY + ty) * LW + x, PACK4(m_u2));
             }
@@ -853,19 +865,18 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
                 }
                 float rr1 = 0.f, rr2 = 0.f;
                 if (x + 4 < W) { rr1 = U2a[(bq * RY + ty) * LW + x + 4]; rr2 = U2b[(bq * RY + ty) * LW + x + 4]; }
-                float dv1[4], dv2[4], r11[4], r12[4], r21[4], r22[4];
+                float dv1[4], dv2[4], r11[4], r12[4], r21[4], r22[4], u1x[4], u1y[4], u2x[4], u2y[4];
                 UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int xi = x + i;
                     const float e1 = i < 3 ? s2_u1[i + 1] : rr1, e2 = i < 3 ? s2_u2[i + 1] : rr2;
-                    const float u1x = xi < W - 1 ? e1 - s2_u1[i] : 0.f;
-                    const float u2x = xi < W - 1 ? e2 - s2_u2[i] : 0.f;
-                    const float u1y = !lastrow ? dv1[i] - s2_u1[i] : 0.f;
-                    const float u2y = !lastrow ? dv2[i] - s2_u2[i] : 0.f;
-                    tv_p_px(a.taut, u1x, u1y, s2_11[i], s2_12[i], r11[i], r12[i]);
-                    tv_p_px(a.taut, u2x, u2y, s2_21[i], s2_22[i], r21[i], r22[i]);
+                    u1x[i] = xi < W - 1 ? e1 - s2_u1[i] : 0.f;
+                    u2x[i] = xi < W - 1 ? e2 - s2_u2[i] : 0.f;
+                    u1y[i] = !lastrow ? dv1[i] - s2_u1[i] : 0.f;
+                    u2y[i] = !lastrow ? dv2[i] - s2_u2[i] : 0.f;
                 }
+                tv_p_quad(a.taut, u1x, u1y, u2x, u2y, s2_11, s2_12, s2_21, s2_22, r11, r12, r21, r22);
                 const size_t prow = (size_t)yc * pitch + x;
                 st4(ou1 + prow, PACK4(s2_u1)); st4(ou2 + prow, PACK4(s2_u2));
                 st4(o11 + prow, PACK4(r11)); st4(o12 + prow, PACK4(r12));
