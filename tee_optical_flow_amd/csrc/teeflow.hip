@@ -69,6 +69,7 @@ struct tf_handle {
     // tuning knobs (tf_set_tuning)
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
+    int force_ry = 0;            // 0 = floor(256/QX) rows per step
     int min_rows_work = 4096;    // rows*pairs below which the tile kernel is used (tiny launches / single-pair latency)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
@@ -209,24 +210,33 @@ bool rows_ok(const tf_handle* h, const Geom& g, int B)
     return h->iter_variant >= 1 && g.w <= 1024 && (long long)g.h * B >= h->min_rows_work;
 }
 
-void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int* RY)
+// Block shape of the row-strip kernels: QX quads per row, RY = floor(256/QX) rows per step, 256 threads.
+// (Measured on MI355X: shapes that fill more lanes with 320-512-thread blocks, or 1-row/128-thread blocks, are 10-35 %
+// SLOWER -- more waves per barrier domain / fewer blocks per CU cost more than idle lanes; "force_ry" keeps the experiment.)
+void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int* RY, int* threads, bool two)
 {
-    *QX = (g.w + 3) / 4; *RY = 256 / *QX;
-    long long n = (long long)g.h * B / ((long long)h->strip_blocks * *RY);
+    (void)two;
+    const int qx = (g.w + 3) / 4;
+    int ry = 256 / qx;
+    if (ry < 1) ry = 1;
+    if (h->force_ry > 0 && qx * h->force_ry <= 512) ry = h->force_ry;
+    *QX = qx; *RY = ry;
+    *threads = qx * ry <= 256 ? 256 : (qx * ry + 63) / 64 * 64;
+    long long n = (long long)g.h * B / ((long long)h->strip_blocks * ry);
     if (n < 2) n = 2;
     if (n > 16) n = 16;
-    *R = *RY * (int)n;
+    *R = ry * (int)n;
 }
 
 // launch one two-iteration tvl1_iter step (k_iter2_rows)
 void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
 {
     const Geom& g = A.a.g;
-    int R, QX, RY;
-    strip_shape(h, g, B, &R, &QX, &RY);
+    int R, QX, RY, threads;
+    strip_shape(h, g, B, &R, &QX, &RY, &threads, true);
     const int LW = QX * 4 + 4;
-    const size_t shmem = (size_t)(16 + 8 * RY * LW + 2 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
-    hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(256), shmem, s, A, R, QX, RY);
+    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
+    hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY);
 }
 
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
@@ -234,11 +244,11 @@ void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 {
     const Geom& g = ia.g;
     if (rows_ok(h, g, B)) {
-        int R, QX, RY;
-        strip_shape(h, g, B, &R, &QX, &RY);
+        int R, QX, RY, threads;
+        strip_shape(h, g, B, &R, &QX, &RY, &threads, false);
         const int LW = QX * 4 + 4;
-        const size_t shmem = (size_t)(8 + 8 * RY * LW + 2 * RY * QX) * sizeof(float);
-        hipLaunchKernelGGL(k_iter_rows, dim3((g.h + R - 1) / R, 1, B), dim3(256), shmem, s, ia, R, QX, RY);
+        const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * RY * QX) * sizeof(float);
+        hipLaunchKernelGGL(k_iter_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, ia, R, QX, RY);
     } else {
         const dim3 gi((g.w + IT_OW - 1) / IT_OW, (g.h + IT_OH - 1) / IT_OH, B);
         hipLaunchKernelGGL(k_iter, gi, dim3(256), 0, s, ia);
@@ -583,6 +593,8 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
     h->stream = h->own_stream;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter2_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute");
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     {
         void* hp = nullptr; void* dp = nullptr;
@@ -689,6 +701,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
     else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
     else if (n == "min_rows_work") h->min_rows_work = value;
+    else if (n == "force_ry") h->force_ry = value;
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
 }

@@ -486,12 +486,12 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
 // quad to the left, u' of the quad to the right and of the row below) goes through LDS; the dual
 // update of a row is deferred by one step until the u' row below it exists.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, int RY)
+__global__ __launch_bounds__(512) void k_iter_rows(IterArgs a, int R, int QX, int RY)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LW = QX * 4 + 4;
-    u64* sred = reinterpret_cast<u64*>(smem);      // 4 x u64 = 32 B, keeps the float arrays 16-B aligned
-    float* su1 = smem + 8;                         // [2][RY][LW]   u1' rows of this / the previous step
+    u64* sred = reinterpret_cast<u64*>(smem);      // 8 x u64 (one per wave, blocks have up to 512 threads)
+    float* su1 = smem + 32;                        // [2][RY][LW]   u1' rows of this / the previous step
     float* su2 = su1 + 2 * RY * LW;
     float* sp12 = su2 + 2 * RY * LW;               // [2][RY][LW]   old p12 rows (the row below reads them)
     float* sp22 = sp12 + 2 * RY * LW;
@@ -616,7 +616,11 @@ __global__ __launch_bounds__(256) void k_iter_rows(IterArgs a, int R, int QX, in
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
     if ((tid & 63) == 0) sred[tid >> 6] = q;
     __syncthreads();
-    if (tid == 0) atomicAdd(&errb[a.it], sred[0] + sred[1] + sred[2] + sred[3]);
+    if (tid == 0) {
+        u64 tot = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += sred[w];
+        atomicAdd(&errb[a.it], tot);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -673,13 +677,13 @@ __device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
 }
 
 
-__global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int QX, int RY)
+__global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, int RY)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IterArgs& a = A.a;
     const int LW = QX * 4 + 4;
-    u64* sred = reinterpret_cast<u64*>(smem);      // 8 x u64 = 64 B
-    float* U1a = smem + 16;                        // [2][RY][LW]  u1 (first iterate) plane 1 / 2
+    u64* sred = reinterpret_cast<u64*>(smem);      // 2 x 8 x u64 = 128 B (one per wave and error sum)
+    float* U1a = smem + 32;                        // [2][RY][LW]  u1 (first iterate) plane 1 / 2
     float* U1b = U1a + 2 * RY * LW;
     float* U2a = U1b + 2 * RY * LW;                // [2][RY][LW]  u2 (second iterate)
     float* U2b = U2a + 2 * RY * LW;
@@ -898,11 +902,13 @@ __global__ __launch_bounds__(256, 2) void k_iter2_rows(Iter2Args A, int R, int Q
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { qA += __shfl_down(qA, off, 64); qB += __shfl_down(qB, off, 64); }
         __syncthreads();
-        if ((tid & 63) == 0) { sred[tid >> 6] = qA; sred[4 + (tid >> 6)] = qB; }
+        if ((tid & 63) == 0) { sred[tid >> 6] = qA; sred[8 + (tid >> 6)] = qB; }
         __syncthreads();
         if (tid == 0) {
-            atomicAdd(&errb[a.it], sred[0] + sred[1] + sred[2] + sred[3]);
-            atomicAdd(&errb[a.it + 1], sred[4] + sred[5] + sred[6] + sred[7]);
+            u64 ta = 0, tb = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += sred[w]; tb += sred[8 + w]; }
+            atomicAdd(&errb[a.it], ta);
+            atomicAdd(&errb[a.it + 1], tb);
         }
     }
 }
