@@ -5,14 +5,30 @@
 #ifndef TEEFLOW_MEDIAN_NET_H
 #define TEEFLOW_MEDIAN_NET_H
 
+#include <type_traits>
+
 #ifndef TF_HD
 #define TF_HD
 #endif
 
 #define TF_CE(a, b) { const T lo_ = tf_min(p[a], p[b]); const T hi_ = tf_max(p[a], p[b]); p[a] = lo_; p[b] = hi_; }
 
-template <typename T> TF_HD inline T tf_min(T a, T b) { return b < a ? b : a; }
-template <typename T> TF_HD inline T tf_max(T a, T b) { return b < a ? a : b; }
+// On the GPU a float min/max is ONE v_min_f32 / v_max_f32 instead of compare + select (no NaNs reach the median and
+// +-0 compare equal downstream); the generic form serves the host-side zero-one proof.
+template <typename T> TF_HD inline T tf_min(T a, T b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<T, float>::value) return __builtin_fminf(a, b);
+#endif
+    return b < a ? b : a;
+}
+template <typename T> TF_HD inline T tf_max(T a, T b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<T, float>::value) return __builtin_fmaxf(a, b);
+#endif
+    return b < a ? a : b;
+}
 
 // 19 compare-exchanges; median lands in p[4]
 template <typename T> TF_HD inline T tf_median9(T* p)

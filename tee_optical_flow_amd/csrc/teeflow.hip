@@ -70,6 +70,8 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
+                                 // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
     int min_rows_work = 4096;    // rows*pairs below which the tile kernel is used (tiny launches / single-pair latency)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
@@ -255,6 +257,23 @@ void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
     }
 }
 
+// k_warp_lds is instantiated for a few margins (the staged width is a compile-time constant)
+inline int warp_margin_class(int m) { return m <= 0 ? 0 : (m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 12 ? 12 : 16))); }
+void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s)
+{
+    const Geom& g = wa.g;
+    const int M = warp_margin_class(h->warp_margin);
+    const dim3 grid((g.w + WL_TW - 1) / WL_TW, (g.h + WL_TH - 1) / WL_TH, B);
+    const size_t shm = (size_t)(128 + (WL_TW + 2 * M + 7) * (WL_TH + 2 * M + 7)) * sizeof(float);
+    switch (M) {
+        case 4: hipLaunchKernelGGL(k_warp_lds<4>, grid, dim3(256), shm, s, wa); break;
+        case 8: hipLaunchKernelGGL(k_warp_lds<8>, grid, dim3(256), shm, s, wa); break;
+        case 12: hipLaunchKernelGGL(k_warp_lds<12>, grid, dim3(256), shm, s, wa); break;
+        case 16: hipLaunchKernelGGL(k_warp_lds<16>, grid, dim3(256), shm, s, wa); break;
+        default: hipLaunchKernelGGL(k_warp, dim3((g.w + 63) / 64, (g.h + 3) / 4, B), dim3(256), 0, s, wa); break;
+    }
+}
+
 // one (level, warp) stage for pairs [0,B)
 int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 {
@@ -268,7 +287,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     WarpArgs wa;
     wa.pyr = h->pyr[l]; wa.off0 = off0; wa.off1 = off1; wa.sb = h->sb; wa.ctl = h->ctl; wa.tab = h->tab;
     wa.wx = h->cwx; wa.wy = h->cwy; wa.rho = h->crho; wa.g = g;
-    hipLaunchKernelGGL(k_warp, grid64x4(g, B), dim3(256), 0, s, wa);
+    launch_warp(h, wa, B, s);
     HIPC(h, hipMemsetAsync(h->errs, 0, (size_t)B * h->errstride * sizeof(u64), s));
 
     IterArgs ia;
@@ -702,6 +721,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
+    else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
 }
@@ -820,7 +840,7 @@ TF_API int tf_dbg_warp(tf_handle* h, const float* I0, const float* I1, const flo
     WarpArgs wa = {};
     wa.pyr = fr; wa.off0 = 0; wa.off1 = 1; wa.sb.u1[0] = du1.p; wa.sb.u2[0] = du2.p; wa.ctl = ctl; wa.tab = h->tab;
     wa.wx = dwx.p; wa.wy = dwy.p; wa.rho = drho.p; wa.g = g;
-    hipLaunchKernelGGL(k_warp, grid64x4(g, 1), dim3(256), 0, h->stream, wa);
+    launch_warp(h, wa, 1, h->stream);
     hipError_t e = hipStreamSynchronize(h->stream);
     (void)hipFree(ctl);
     if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_warp: %s", hipGetErrorString(e));

@@ -212,6 +212,116 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_warp_lds: same arithmetic as k_warp, but the 36 taps of a pixel come from an LDS copy of the I1 tile plus a margin
+// of M pixels (k_warp is L1/TA-bound on its 36 scalar gathers per pixel; ds_read_b32 from a staged tile is ~7x cheaper).
+// A pixel whose 6x6 footprint leaves the staged region (|flow| > ~M) falls back to clamped global loads, so the result
+// never depends on M.  The staged array holds I1 at UNclamped coordinates with replicate content, which is exactly what
+// the clamped patch loads of k_warp read.
+// ---------------------------------------------------------------------------------------------
+#define WL_TW 64
+#define WL_TH 16
+
+__device__ __forceinline__ void warp_accumulate(const float (&P)[6][6], const float* wxp, const float* wyp, int ix, int iy, int W, int H,
+                                                float& vI, float& vX, float& vY)
+{
+    float wgt[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) wgt[k1 * 4 + k2] = wyp[k1] * wxp[k2];
+    const unsigned width1 = (unsigned)(W - 3 > 0 ? W - 3 : 0), height1 = (unsigned)(H - 3 > 0 ? H - 3 : 0);
+    vI = vX = vY = 0.f;
+    if ((unsigned)ix < width1 && (unsigned)iy < height1) {
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            float rI = P[k1 + 1][1] * wgt[k1 * 4];
+            float rX = (0.5f * (P[k1 + 1][2] - P[k1 + 1][0])) * wgt[k1 * 4];
+            float rY = (0.5f * (P[k1 + 2][1] - P[k1][1])) * wgt[k1 * 4];
+#pragma unroll
+            for (int k2 = 1; k2 < 4; ++k2) {
+                rI = rI + P[k1 + 1][k2 + 1] * wgt[k1 * 4 + k2];
+                rX = rX + (0.5f * (P[k1 + 1][k2 + 2] - P[k1 + 1][k2])) * wgt[k1 * 4 + k2];
+                rY = rY + (0.5f * (P[k1 + 2][k2 + 1] - P[k1][k2 + 1])) * wgt[k1 * 4 + k2];
+            }
+            if (k1 == 0) { vI = rI; vX = rX; vY = rY; }
+            else { vI += rI; vX += rX; vY += rY; }
+        }
+    } else {
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            const int yi = iy + k1;
+            if (yi < 0 || yi >= H) continue;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int xj = ix + k2;
+                if (xj < 0 || xj >= W) continue;
+                vI += P[k1 + 1][k2 + 1] * wgt[k1 * 4 + k2];
+                vX += (0.5f * (P[k1 + 1][k2 + 2] - P[k1 + 1][k2])) * wgt[k1 * 4 + k2];
+                vY += (0.5f * (P[k1 + 2][k2 + 1] - P[k1][k2 + 1])) * wgt[k1 * 4 + k2];
+            }
+        }
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void k_warp_lds(WarpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* stab = smem;                  // [128] bicubic table
+    float* S = smem + 128;               // [SH][SW] staged I1
+    constexpr int SW = WL_TW + 2 * M + 7, SH = WL_TH + 2 * M + 7;      // compile-time: i / SW below is a multiply-shift
+    const int b = blockIdx.z;
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    const int x0 = blockIdx.x * WL_TW, y0 = blockIdx.y * WL_TH;
+    const int rx0 = x0 - M - 3, ry0 = y0 - M - 3;
+    const float* __restrict__ I0 = a.pyr + (size_t)(a.off0 + b) * a.g.plane;
+    const float* __restrict__ I1 = a.pyr + (size_t)(a.off1 + b) * a.g.plane;
+    if (threadIdx.x < 128) stab[threadIdx.x] = a.tab[threadIdx.x];
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        S[i] = I1[(size_t)clampi(ry0 + ly, 0, H - 1) * pitch + clampi(rx0 + lx, 0, W - 1)];
+    }
+    __syncthreads();
+    const int uc = a.ctl[b].ubase & 1;
+    const size_t po = (size_t)b * a.g.splane;
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+    if (x >= W) return;
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + (threadIdx.x >> 6) + 4 * r;
+        if (y >= H) break;
+        const size_t idx = (size_t)y * pitch + x;
+        const float u1 = a.sb.u1[uc][po + idx], u2 = a.sb.u2[uc][po + idx];
+        const float mx = (float)x + u1, my = (float)y + u2;
+        const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
+        const float* wxp = stab + (sx & 31) * 4;
+        const float* wyp = stab + (sy & 31) * 4;
+        const int ix = clampi(sx >> 5, -32768, 32767) - 1, iy = clampi(sy >> 5, -32768, 32767) - 1;   // saturate_cast<short>
+        float vI = 0.f, vX = 0.f, vY = 0.f;
+        if (!(ix >= W || ix + 4 <= 0 || iy >= H || iy + 4 <= 0)) {
+            float P[6][6];
+            const int px = ix - 1 - rx0, py = iy - 1 - ry0;
+            if (px >= 0 && py >= 0 && px + 6 <= SW && py + 6 <= SH) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) P[j][i] = S[(py + j) * SW + px + i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float* row = I1 + (size_t)clampi(iy - 1 + j, 0, H - 1) * pitch;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) P[j][i] = row[clampi(ix - 1 + i, 0, W - 1)];
+                }
+            }
+            warp_accumulate(P, wxp, wyp, ix, iy, W, H, vI, vX, vY);
+        }
+        a.wx[po + idx] = vX;
+        a.wy[po + idx] = vY;
+        a.rho[po + idx] = ((vI - vX * u1) - vY * u2) - I0[idx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cv::medianBlur(u, u, KS) on both flow planes, BORDER_REPLICATE, for pairs still iterating.
 // Tile 64x16 outputs per 256-thread block, staged through LDS with its halo; grid.z = 2*B.
 // ---------------------------------------------------------------------------------------------
@@ -234,9 +344,9 @@ __global__ __launch_bounds__(256) void k_median(MedArgs a)
     const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
     float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
     const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int ly = i / LW, lx = i - ly * LW;
-        t[ly][lx] = src[(size_t)clampi(y0 - R + ly, 0, H - 1) * pitch + clampi(x0 - R + lx, 0, W - 1)];
+    for (int ly = threadIdx.x >> 6; ly < LH; ly += 4) {
+        const float* row = src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch;
+        for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
     }
     __syncthreads();
     const int lx = threadIdx.x & 63, x = x0 + lx;
@@ -926,9 +1036,9 @@ __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
     const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
     float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
     const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int ly = i / LW, lx = i - ly * LW;
-        t[ly][lx] = src[(size_t)clampi(y0 - R + ly, 0, H - 1) * pitch + clampi(x0 - R + lx, 0, W - 1)];
+    for (int ly = threadIdx.x >> 6; ly < LH; ly += 4) {
+        const float* row = src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch;
+        for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
     }
     __syncthreads();
     const int lx = threadIdx.x & 63, x = x0 + lx;

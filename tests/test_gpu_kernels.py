@@ -47,9 +47,10 @@ def test_flow_upsample_resize_bit_exact(engine, oracle, src_shape, dst_shape):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("margin", [0, 2, 8])
 @pytest.mark.parametrize("shape,amp", [((64, 64), 3.0), ((97, 131), 8.0), ((210, 210), 1.0), ((40, 300), 60.0),
                                        ((20, 18), 30.0)])
-def test_warp_bit_exact(engine, oracle, shape, amp):
+def test_warp_bit_exact(engine, oracle, shape, amp, margin):
     """buildFlowMap + 3x remap(INTER_CUBIC, BORDER_CONSTANT) + calcGradRho; `amp` pushes samples across and
     beyond the borders (partial-tap and fully-outside cases)."""
     from tee_optical_flow_amd import _lib
@@ -63,11 +64,13 @@ def test_warp_bit_exact(engine, oracle, shape, amp):
     u2[-1, -1] = -1e6
     r_wx, r_wy, r_grad, r_rho = oracle.warp(I0, I1, u1, u2)
     wx, wy, rho = (np.empty((h, w), np.float32) for _ in range(3))
+    engine.set_tuning("warp_margin", margin)   # 0: global gathers; >0: LDS-staged tile + margin with global fallback
     _lib.check(L.tf_dbg_warp(engine._h, _ptr(I0), _ptr(I1), _ptr(u1), _ptr(u2), w, h, _ptr(wx), _ptr(wy), _ptr(rho)), engine._h)
     assert np.array_equal(wx, r_wx)
     assert np.array_equal(wy, r_wy)
     assert np.array_equal(rho, r_rho)
     assert np.array_equal(wx * wx + wy * wy, r_grad)   # |grad|^2 is recomputed in tvl1_iter, never stored
+    engine.set_tuning("warp_margin", 0)
 
 
 @pytest.mark.parametrize("ksize", [3, 5])
