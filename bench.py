@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket tvl1_iter launches with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
 
     import torch
@@ -85,18 +87,24 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    if a.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     B, H, W = a.batch, a.size, a.size
     seeds = list(range(rank * B, (rank + 1) * B))      # rank r owns pairs [rB, (r+1)B): no data-path exchange
     I0s, I1s = make_inputs(seeds, H, W)
     frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)       # [2B,H,W] u8, resident in HBM
     flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    gdev = dev if a.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
     eng = T.DenseFlow(device_id=local_rank, max_batch=B)
     # the engine runs on its own non-blocking HIP stream (its per-launch events are recorded there); every call is
     # host-synchronous, so torch-side consumers (the RCCL all-gather) may start right after it returns
@@ -111,7 +119,8 @@ def main():
             pending[buf] = None
         st = eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
         if world > 1:
-            pending[buf] = dist.all_gather_into_tensor(gathered[buf], flows[buf], async_op=True)
+            src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
         return st
 
     def drain():
@@ -140,7 +149,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # Roofline leg: the SAME K steps again with every tvl1_iter launch bracketed by a HIP event pair on the engine's
@@ -178,10 +187,13 @@ def main():
                                    "5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; inputs resident in HBM; "
                                    + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
                        "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_iter (tvl1_iter)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_iter2_rows (tvl1_iter, two inner iterations per launch)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "launches": acc["iter_launches"], "bytes_per_px_iteration": 60,
+                         "note": "achieved = executed pair-iterations x px x 60 B (the single-iteration kernel's compulsory traffic) / summed launch "
+                                 "time; the launched kernel fuses two iterations, so its real HBM traffic (`traffic`, PMC) is about half of that "
+                                 "and the kernel is bound by fp32/fp64 VALU issue (see DESIGN.md section 4)",
                          "measured_on": f"{a.steps} instrumented repeats of the timed steps (one HIP event pair per launch, engine stream)"},
             "executed_inner_iterations_per_pair": acc["inner"] / (B * a.steps),
             "executed_outer_iterations_per_pair": acc["outer"] / (B * a.steps),
