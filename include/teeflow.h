@@ -43,7 +43,7 @@ enum {
     TF_ERR_NO_DEVICE = 5      /* no gfx950 device visible: there is NO CPU fallback */
 };
 
-enum { TF_ALGO_TVL1 = 0, TF_ALGO_DEEPFLOW = 1 /* reserved, SURVEY.md row a6 */ };
+enum { TF_ALGO_TVL1 = 0, TF_ALGO_DEEPFLOW = 1 /* handles come from tf_create_deepflow */ };
 
 /* keys for tf_set_param / tf_get_param: the 12 cv2.DualTVL1OpticalFlow setters */
 enum {
@@ -87,6 +87,23 @@ int tf_default_params(tf_params* p);
 /* replaces createOptFlow_DualTVL1() / cuda.OpticalFlowDual_TVL1.create()  (calculate_optical_flow.py:575,577) */
 int tf_create(const tf_params* p, int device_id, tf_handle** out);
 void tf_destroy(tf_handle* h);
+
+/* cv2.optflow.createOptFlow_DeepFlow() (calculate_optical_flow.py:568) and its OpticalFlowDeepFlow constants; the cv2
+ * object exposes no setters in Python, so these are creation-time only.  The handle is used with the same tf_calc_*
+ * entry points (OF_model.calc(...), calculate_optical_flow.py:631). */
+typedef struct tf_deepflow_params {
+    float sigma;                  /* 0.6  Gaussian pre-blur */
+    int min_size;                 /* 25   smallest pyramid side */
+    float downscale_factor;       /* 0.95 */
+    int fixed_point_iterations;   /* 5 */
+    int sor_iterations;           /* 25 */
+    float alpha, delta, gamma;    /* 1.0, 0.5, 5.0 (VariationalRefinement gets 4*alpha, delta/3, gamma/3) */
+    float omega;                  /* 1.6 */
+    float zeta, epsilon;          /* 0.1, 0.001 (cv::VariationalRefinement internals) */
+    int max_batch;                /* pairs resident per sub-batch (0 = default 128) */
+} tf_deepflow_params;
+int tf_default_deepflow_params(tf_deepflow_params* p);
+int tf_create_deepflow(const tf_deepflow_params* p, int device_id, tf_handle** out);
 
 /* replaces OF_model.setLambda(...) and the 11 sibling setters / getters  (calculate_optical_flow.py:578) */
 int tf_set_param(tf_handle* h, int key, double value);
@@ -134,6 +151,9 @@ int tf_device_count(void);
  * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
  * stop reports). Results never change. */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
+/* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
+int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);
+int tf_dbg_df_blur(tf_handle* h, const float* src, int w, int hgt, float* dst);
 int tf_dbg_pyramid(tf_handle* h, const uint8_t* img, int H, int W, int level, float* out, int* ow, int* oh);
 int tf_dbg_resize(tf_handle* h, const float* src, int sw, int sh, float* dst, int dw, int dh,
                   double inv_scale_x, double inv_scale_y, float mul);

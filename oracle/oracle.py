@@ -203,3 +203,100 @@ def pyramid_level(img, level, scale_step=0.8):
     lib().orc_pyramid_level(img, h, w, float(scale_step), int(level), out.ctypes.data_as(C.c_void_p),
                             C.byref(ow), C.byref(oh))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# DeepFlow oracle (oracle/deepflow_oracle.c) -- same rules: test infrastructure only
+# ----------------------------------------------------------------------------------------------------------------------
+class DfoParams(C.Structure):
+    _fields_ = [("sigma", C.c_float), ("min_size", C.c_int), ("downscale_factor", C.c_float),
+                ("fixed_point_iterations", C.c_int), ("sor_iterations", C.c_int), ("alpha", C.c_float), ("delta", C.c_float),
+                ("gamma", C.c_float), ("omega", C.c_float), ("zeta", C.c_float), ("epsilon", C.c_float)]
+
+
+_dlib = None
+
+
+def dlib():
+    global _dlib
+    if _dlib is None:
+        build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+        L = C.CDLL(os.path.join(_HERE, "libdeepflow_oracle.so"))
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        L.dfo_default_params.argtypes = [C.POINTER(DfoParams)]
+        L.dfo_resize_linear.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.dfo_gauss3.argtypes = [C.c_float, fp]
+        L.dfo_gauss_blur3.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp]
+        L.dfo_warp_linear.argtypes = [fp, C.c_int, C.c_int, fp, fp, fp]
+        L.dfo_derivatives.argtypes = [fp, fp, C.c_int, C.c_int, fp, fp] + [fp] * 8
+        L.dfo_variational_refine.argtypes = [C.POINTER(DfoParams), C.c_float, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, fp, fp]
+        L.dfo_pyramid_sizes.argtypes = [C.POINTER(DfoParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.dfo_pyramid_sizes.restype = C.c_int
+        L.dfo_deepflow_calc.argtypes = [C.POINTER(DfoParams), u8p, u8p, C.c_int, C.c_int, fp]
+        L.dfo_deepflow_calc.restype = C.c_int
+        lib()  # sets the OpenMP team size once for the process (shared libgomp)
+        _dlib = L
+    return _dlib
+
+
+def deepflow_default_params(**over):
+    p = DfoParams()
+    dlib().dfo_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def deepflow_pyramid_sizes(W, H, params=None):
+    p = params if params is not None else deepflow_default_params()
+    ws = np.zeros(256, np.int32)
+    hs = np.zeros(256, np.int32)
+    n = dlib().dfo_pyramid_sizes(C.byref(p), int(W), int(H), ws.ctypes.data_as(C.c_void_p), hs.ctypes.data_as(C.c_void_p), 256)
+    return list(zip(ws[:n].tolist(), hs[:n].tolist()))
+
+
+def deepflow_gauss_blur3(src, sigma=0.6):
+    src = _f32(src)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    dlib().dfo_gauss_blur3(src, w, h, float(sigma), dst)
+    return dst
+
+
+def deepflow_warp_linear(I1, u, v):
+    I1, u, v = map(_f32, (I1, u, v))
+    h, w = I1.shape
+    dst = np.empty_like(I1)
+    dlib().dfo_warp_linear(I1, w, h, u, v, dst)
+    return dst
+
+
+def deepflow_derivatives(I0, I1, u, v):
+    I0, I1, u, v = map(_f32, (I0, I1, u, v))
+    h, w = I0.shape
+    outs = [np.empty_like(I0) for _ in range(8)]
+    dlib().dfo_derivatives(I0, I1, w, h, u, v, *outs)
+    return outs   # Ix, Iy, Iz, Ixx, Ixy, Iyy, Ixz, Iyz
+
+
+def deepflow_variational_refine(I0, I1, u, v, alpha=4.0, delta=0.5 / 3, gamma=5.0 / 3, params=None):
+    p = params if params is not None else deepflow_default_params()
+    I0, I1 = _f32(I0), _f32(I1)
+    u, v = _f32(u).copy(), _f32(v).copy()
+    h, w = I0.shape
+    dlib().dfo_variational_refine(C.byref(p), np.float32(alpha), np.float32(delta), np.float32(gamma), I0, I1, w, h, u, v)
+    return u, v
+
+
+def deepflow_calc(I0, I1, params=None, return_levels=False):
+    I0 = np.ascontiguousarray(I0, dtype=np.uint8)
+    I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+    p = params if params is not None else deepflow_default_params()
+    h, w = I0.shape
+    flow = np.empty((h, w, 2), np.float32)
+    n = dlib().dfo_deepflow_calc(C.byref(p), I0, I1, h, w, flow.reshape(-1))
+    if n <= 0:
+        raise RuntimeError(f"dfo_deepflow_calc failed rc={n}")
+    return (flow, n) if return_levels else flow

@@ -19,7 +19,8 @@ EXPORTED_SYMBOLS = [
     "tf_abi_version", "tf_device_count", "tf_default_params", "tf_create", "tf_destroy", "tf_set_param",
     "tf_get_param", "tf_set_stream", "tf_set_profile", "tf_calc_pair", "tf_calc_seq", "tf_calc_pairs",
     "tf_calc_pairs_device", "tf_calc_seq_device", "tf_get_iters", "tf_last_error",
-    "tf_set_tuning", "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
+    "tf_set_tuning", "tf_default_deepflow_params", "tf_create_deepflow", "tf_dbg_df_refine", "tf_dbg_df_blur",
+    "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
 ]
 
 
@@ -28,6 +29,12 @@ class TfParams(C.Structure):
                 ("scale_step", C.c_double), ("gamma", C.c_double), ("nscales", C.c_int), ("warps", C.c_int),
                 ("inner_iterations", C.c_int), ("outer_iterations", C.c_int), ("median_filtering", C.c_int),
                 ("use_initial_flow", C.c_int), ("algo", C.c_int), ("max_batch", C.c_int)]
+
+
+class TfDeepflowParams(C.Structure):
+    _fields_ = [("sigma", C.c_float), ("min_size", C.c_int), ("downscale_factor", C.c_float), ("fixed_point_iterations", C.c_int),
+                ("sor_iterations", C.c_int), ("alpha", C.c_float), ("delta", C.c_float), ("gamma", C.c_float), ("omega", C.c_float),
+                ("zeta", C.c_float), ("epsilon", C.c_float), ("max_batch", C.c_int)]
 
 
 class TfStats(C.Structure):
@@ -66,6 +73,10 @@ def load():
     L.tf_set_stream.argtypes = [vp, vp, i32]
     L.tf_set_profile.argtypes = [vp, i32]
     L.tf_set_tuning.argtypes = [vp, C.c_char_p, i32]
+    L.tf_default_deepflow_params.argtypes = [C.POINTER(TfDeepflowParams)]
+    L.tf_create_deepflow.argtypes = [C.POINTER(TfDeepflowParams), i32, C.POINTER(vp)]
+    L.tf_dbg_df_refine.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    L.tf_dbg_df_blur.argtypes = [vp, vp, i32, i32, vp]
     L.tf_calc_pair.argtypes = [vp, vp, vp, i32, i32, vp, C.POINTER(TfStats)]
     L.tf_calc_seq.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
     L.tf_calc_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.POINTER(TfStats)]

@@ -11,6 +11,7 @@
 // each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
+#include "teeflow_deepflow.hip.h"
 #include "../../include/teeflow.h"
 
 #include <chrono>
@@ -27,6 +28,7 @@
 namespace {
 
 constexpr int MAXLEV = 64;
+constexpr int DF_MAXLEV = 160;       // x0.95 pyramid: 60 levels at 512^2, 87 at 2048^2
 constexpr int SLOT_RING = 1024;       // host-mapped words the tvl1_iter launches publish their active-pair count to
 constexpr int DEFAULT_LAG = 3;        // the host enqueues at most this many launches beyond the last answer it has read
 constexpr int DEFAULT_MAX_BATCH = 128;
@@ -66,6 +68,14 @@ struct tf_handle {
     std::vector<int> last_iters; int last_pairs = 0, last_nlev = 0, last_warps = 0;
     // per-call accumulators
     unsigned long long iter_launches = 0;
+    // ---- DeepFlow (algo == TF_ALGO_DEEPFLOW) ----
+    tf_deepflow_params DP = {};
+    int dnlev = 0, dH = 0, dW = 0, dcap = 0;
+    Geom dlv[DF_MAXLEV];
+    float* dpyr_base = nullptr; size_t dpyr_off[DF_MAXLEV] = {};   // one allocation: level l of frame f at dpyr_base + off[l] + f*plane_l
+    float* dtmp = nullptr;                                          // unblurred level-0 frames
+    float* dplanes = nullptr;                                       // 21 state planes x cap pairs
+    DfBufs df = {};
     // tuning knobs (tf_set_tuning)
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
@@ -136,6 +146,8 @@ void free_buffers(tf_handle* h)
     for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
     F(h->ctl); F(h->errs); F(h->iters_dev);
     F(h->st_u8); F(h->st_flow);
+    F(h->dpyr_base); F(h->dtmp); F(h->dplanes);
+    h->dnlev = h->dH = h->dW = h->dcap = 0;
     h->st_u8_bytes = h->st_flow_bytes = 0;
     h->H = h->W = h->cap = h->nlev = 0; h->iters_cap = 0;
 }
@@ -460,6 +472,142 @@ void account_bytes(const tf_handle* h, const int* it /* [nlev][warps][2] */, dou
     *iter_bytes += ib; *total_bytes += tb + ib;
 }
 
+// =================================================================================================
+// DeepFlow host side
+// =================================================================================================
+int df_levels(const tf_deepflow_params& P, int H, int W, Geom* lv)
+{
+    int n = 1;
+    lv[0] = make_geom(W, H);
+    while (n < DF_MAXLEV) {
+        // Size((int)(cols*downscaleFactor + 0.5f), (int)(rows*downscaleFactor + 0.5f)), float arithmetic
+        const int nw = (int)(lv[n - 1].w * P.downscale_factor + 0.5f), nh = (int)(lv[n - 1].h * P.downscale_factor + 0.5f);
+        if (nh <= P.min_size || nw <= P.min_size) break;
+        lv[n] = make_geom(nw, nh);
+        lv[n].splane = lv[0].plane;
+        ++n;
+    }
+    return n;
+}
+
+int df_validate(tf_handle* h, const tf_deepflow_params& p)
+{
+    if (!(p.sigma > 0.f) || (int)floorf(3 * p.sigma) * 2 + 1 != 3)
+        return fail(h, TF_ERR_UNSUPPORTED, "DeepFlow pre-blur: only the 3x3 kernel (1/3 <= sigma < 2/3) is implemented, sigma=%g", p.sigma);
+    if (!(p.downscale_factor > 0.1f && p.downscale_factor < 1.f)) return fail(h, TF_ERR_INVALID_ARG, "downscaleFactor must be in (0.1,1)");
+    if (p.min_size < 1 || p.fixed_point_iterations < 0 || p.sor_iterations < 0 || p.fixed_point_iterations > 1000 || p.sor_iterations > 10000)
+        return fail(h, TF_ERR_INVALID_ARG, "bad DeepFlow iteration/size parameters");
+    return TF_OK;
+}
+
+int df_ensure_alloc(tf_handle* h, int H, int W, int B)
+{
+    const int mb = h->DP.max_batch > 0 ? h->DP.max_batch : DEFAULT_MAX_BATCH;
+    const int want = B < mb ? B : mb;
+    if (h->dH == H && h->dW == W && h->dcap >= want) return TF_OK;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    free_buffers(h);
+    h->dnlev = df_levels(h->DP, H, W, h->dlv);
+    const size_t cap = (size_t)want, F = 2 * cap;
+    size_t total = 0;
+    for (int l = 0; l < h->dnlev; ++l) { h->dpyr_off[l] = total; total += F * (size_t)h->dlv[l].plane; }
+    HIPC(h, hipMalloc(&h->dpyr_base, total * sizeof(float)));
+    HIPC(h, hipMalloc(&h->dtmp, F * (size_t)h->dlv[0].plane * sizeof(float)));
+    const size_t pl = (size_t)h->dlv[0].plane * cap;
+    HIPC(h, hipMalloc(&h->dplanes, 21 * pl * sizeof(float)));
+    float* p = h->dplanes;
+    DfBufs& d = h->df;
+    float** slots[] = {&d.avg, &d.Iz, &d.Ix, &d.Iy, &d.Ixx, &d.Ixy, &d.Iyy, &d.Ixz, &d.Iyz, &d.A11, &d.A12, &d.A22, &d.b1, &d.b2, &d.wg,
+                       &d.du, &d.dv, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
+    for (auto s_ : slots) { *s_ = p; p += pl; }
+    h->dH = H; h->dW = W; h->dcap = want;
+    return TF_OK;
+}
+
+DfConst df_consts(const tf_deepflow_params& P)
+{
+    // OpticalFlowDeepFlow::calc: var->setAlpha(4*alpha); setDelta(delta/3); setGamma(gamma/3)
+    const float alpha = 4 * P.alpha, delta = P.delta / 3, gamma = P.gamma / 3;
+    DfConst c;
+    c.zeta2 = P.zeta * P.zeta; c.eps2 = P.epsilon * P.epsilon;
+    c.delta2 = delta / 2; c.gamma2 = gamma / 2; c.alpha2 = alpha / 2; c.omega = P.omega;
+    return c;
+}
+
+void df_gauss3(float sigma, float* k0, float* k1)
+{
+    // getGaussianKernel(3, sigma, CV_32F): normalised in double, cast to float
+    const double s2 = -0.5 / ((double)sigma * (double)sigma);
+    const double t0 = exp(s2 * 1.0), t1 = exp(0.0);
+    const double inv = 1.0 / (t0 + t1 + t0);
+    *k0 = (float)(t1 * inv); *k1 = (float)(t0 * inv);
+}
+
+// one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
+void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const Geom& g, int cur, int B, hipStream_t s)
+{
+    const DfBufs& d = h->df;
+    const DfConst c = df_consts(h->DP);
+    const dim3 gr = grid64x4(g, B), bl(256);
+    const dim3 gsor(((g.w + 1) / 2 + 63) / 64, (g.h + 3) / 4, B);
+    hipLaunchKernelGGL(k_df_warp, gr, bl, 0, s, pyr_l, off0, off1, d, cur, g);
+    hipLaunchKernelGGL(k_df_grad1, gr, bl, 0, s, d, g);
+    hipLaunchKernelGGL(k_df_grad2, gr, bl, 0, s, d, g);
+    for (int fp = 0; fp < h->DP.fixed_point_iterations; ++fp) {
+        hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
+        hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
+        for (int it = 0; it < h->DP.sor_iterations; ++it) {
+            hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 0, c.omega);
+            hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 1, c.omega);
+        }
+    }
+    hipLaunchKernelGGL(k_df_sum, gr, bl, 0, s, d, cur, g);
+}
+
+int df_solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0, int off1, float scale, float* dflow)
+{
+    hipStream_t s = h->stream;
+    const Geom g0 = h->dlv[0];
+    float k0, k1;
+    df_gauss3(h->DP.sigma, &k0, &k1);
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->dtmp, g0);
+    hipLaunchKernelGGL(k_df_blur, grid64x4(g0, F), dim3(256), 0, s, h->dtmp, h->dpyr_base + h->dpyr_off[0], g0, k0, k1);
+    for (int l = 1; l < h->dnlev; ++l) {
+        const Geom gs = h->dlv[l - 1], gd = h->dlv[l];
+        const double sx = 1.0 / ((double)gd.w / gs.w), sy = 1.0 / ((double)gd.h / gs.h);
+        hipLaunchKernelGGL(k_pyr_down, grid64x4(gd, F), dim3(256), 0, s, h->dpyr_base + h->dpyr_off[l - 1], gs, h->dpyr_base + h->dpyr_off[l], gd, sx, sy);
+    }
+    const int L = h->dnlev - 1;
+    int cur = 0;
+    HIPC(h, hipMemset2DAsync(h->df.Wu[0], (size_t)g0.plane * sizeof(float), 0, (size_t)h->dlv[L].plane * sizeof(float), B, s));
+    HIPC(h, hipMemset2DAsync(h->df.Wv[0], (size_t)g0.plane * sizeof(float), 0, (size_t)h->dlv[L].plane * sizeof(float), B, s));
+    const float mul = 1.0f / h->DP.downscale_factor;
+    for (int l = L; l >= 0; --l) {
+        const Geom g = h->dlv[l];
+        df_refine_level(h, h->dpyr_base + h->dpyr_off[l], off0, off1, g, cur, B, s);
+        if (l == 0) break;
+        const Geom gd = h->dlv[l - 1];
+        const double sx = 1.0 / ((double)gd.w / g.w), sy = 1.0 / ((double)gd.h / g.h);
+        hipLaunchKernelGGL(k_df_up, grid64x4(gd, B), dim3(256), 0, s, h->df, cur, g, gd, sx, sy, mul);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_df_out, grid64x4(g0, B), dim3(256), 0, s, h->df, g0, scale, dflow);
+    HIPC(h, hipGetLastError());
+    return TF_OK;
+}
+
+// algorithmic bytes of one DeepFlow pair (fp32 planes touched once per kernel)
+double df_account_bytes(const tf_handle* h)
+{
+    double tb = 0;
+    for (int l = 0; l < h->dnlev; ++l) {
+        const double px = (double)h->dlv[l].w * h->dlv[l].h;
+        const double per_fp = (10 + 3 + 6) * 4.0 /*data*/ + (4 + 3 + 4) * 4.0 /*smooth*/ + h->DP.sor_iterations * 2 * 10 * 4.0 /*SOR colour passes*/;
+        tb += px * ((4 + 4) * 4.0 /*warp*/ + (2 + 4 + 2 + 3) * 4.0 /*grads*/ + h->DP.fixed_point_iterations * per_fp + 6 * 4.0 /*sum*/ + 4 * 4.0 /*up*/);
+    }
+    return tb;
+}
+
 enum Mode { MODE_PAIRS, MODE_SEQ };
 
 // common driver: device==true -> in/out pointers are device memory
@@ -470,15 +618,17 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     if (!in0 || (mode == MODE_PAIRS && !in1) || !flow_out) return fail(h, TF_ERR_INVALID_ARG, "null image/flow pointer");
     if (H < 1 || W < 1 || n_pairs < 1) return fail(h, TF_ERR_INVALID_ARG, "bad sizes: pairs=%d H=%d W=%d", n_pairs, H, W);
     if ((long long)H * W > (1LL << 24)) return fail(h, TF_ERR_UNSUPPORTED, "images above 2^24 pixels are not supported");
-    int rc = validate_params(h, h->P);
+    const bool deep = h->P.algo == TF_ALGO_DEEPFLOW;
+    int rc = deep ? df_validate(h, h->DP) : validate_params(h, h->P);
     if (rc) return rc;
     HIPC(h, hipSetDevice(h->dev));
     const double t0 = now_ms();
-    rc = ensure_alloc(h, H, W, n_pairs);
+    rc = deep ? df_ensure_alloc(h, H, W, n_pairs) : ensure_alloc(h, H, W, n_pairs);
     if (rc) return rc;
+    if (deep) h->cap = h->dcap;
     const size_t fpx = (size_t)H * W;
-    h->last_iters.assign((size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
-    h->last_pairs = n_pairs; h->last_nlev = h->nlev; h->last_warps = h->P.warps;
+    h->last_iters.assign(deep ? 0 : (size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
+    h->last_pairs = n_pairs; h->last_nlev = deep ? h->dnlev : h->nlev; h->last_warps = deep ? 0 : h->P.warps;
     h->iter_launches = 0; h->prof_used = 0;
     float ms_h2d = 0, ms_dev = 0, ms_d2h = 0;
     if (!device) {
@@ -507,13 +657,14 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         }
         dfl = device ? flow_out + (size_t)c0 * fpx * 2 : h->st_flow;
         HIPC(h, hipEventRecord(h->ev[1], h->stream));
-        rc = solve_resident(h, dfr, F, nb, off0, off1, scale, dfl);
+        rc = deep ? df_solve_resident(h, dfr, F, nb, off0, off1, scale, dfl) : solve_resident(h, dfr, F, nb, off0, off1, scale, dfl);
         if (rc) return rc;
         HIPC(h, hipEventRecord(h->ev[2], h->stream));
         if (!device)
             HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * fpx * 2, h->st_flow, (size_t)nb * fpx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIPC(h, hipMemcpyAsync(h->last_iters.data() + (size_t)c0 * h->nlev * h->P.warps * 2, h->iters_dev,
-                               (size_t)nb * h->nlev * h->P.warps * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (!deep)
+            HIPC(h, hipMemcpyAsync(h->last_iters.data() + (size_t)c0 * h->nlev * h->P.warps * 2, h->iters_dev,
+                                   (size_t)nb * h->nlev * h->P.warps * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPC(h, hipEventRecord(h->ev[3], h->stream));
         HIPC(h, hipStreamSynchronize(h->stream));
         float t;
@@ -523,10 +674,11 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     }
     if (st) {
         memset(st, 0, sizeof *st);
-        st->n_pairs = n_pairs; st->nscales_used = h->nlev; st->warps = h->P.warps;
+        st->n_pairs = n_pairs; st->nscales_used = deep ? h->dnlev : h->nlev; st->warps = deep ? 0 : h->P.warps;
         st->ms_h2d = ms_h2d; st->ms_device = ms_dev; st->ms_d2h = ms_d2h;
         st->iter_launches = h->iter_launches;
-        for (int b = 0; b < n_pairs; ++b)
+        if (deep) st->total_bytes = df_account_bytes(h) * n_pairs;
+        for (int b = 0; !deep && b < n_pairs; ++b)
             account_bytes(h, h->last_iters.data() + (size_t)b * h->nlev * h->P.warps * 2, &st->iter_bytes, &st->total_bytes,
                           &st->inner_iters_total, &st->outer_iters_total);
         st->iter_pair_steps = st->inner_iters_total;
@@ -583,6 +735,27 @@ TF_API int tf_default_params(tf_params* p)
     p->tau = 0.25; p->lambda = 0.15; p->theta = 0.3; p->epsilon = 0.01; p->scale_step = 0.8; p->gamma = 0.0;
     p->nscales = 5; p->warps = 5; p->inner_iterations = 30; p->outer_iterations = 10; p->median_filtering = 5;
     p->use_initial_flow = 0; p->algo = TF_ALGO_TVL1; p->max_batch = 0;
+    return TF_OK;
+}
+
+TF_API int tf_default_deepflow_params(tf_deepflow_params* p)
+{
+    if (!p) return TF_ERR_INVALID_ARG;
+    p->sigma = 0.6f; p->min_size = 25; p->downscale_factor = 0.95f; p->fixed_point_iterations = 5; p->sor_iterations = 25;
+    p->alpha = 1.0f; p->delta = 0.5f; p->gamma = 5.0f; p->omega = 1.6f; p->zeta = 0.1f; p->epsilon = 0.001f; p->max_batch = 0;
+    return TF_OK;
+}
+
+TF_API int tf_create_deepflow(const tf_deepflow_params* p, int device_id, tf_handle** out)
+{
+    tf_deepflow_params dp;
+    if (p) dp = *p; else tf_default_deepflow_params(&dp);
+    int rc = df_validate(nullptr, dp);
+    if (rc) return rc;
+    rc = tf_create(nullptr, device_id, out);
+    if (rc) return rc;
+    (*out)->P.algo = TF_ALGO_DEEPFLOW;
+    (*out)->DP = dp;
     return TF_OK;
 }
 
@@ -660,6 +833,7 @@ TF_API void tf_destroy(tf_handle* h)
 TF_API int tf_set_param(tf_handle* h, int key, double v)
 {
     if (!h) return TF_ERR_INVALID_ARG;
+    if (h->P.algo == TF_ALGO_DEEPFLOW) return fail(h, TF_ERR_UNSUPPORTED, "DeepFlow handles have creation-time parameters only (as cv2's object)");
     tf_params p = h->P;
     switch (key) {
         case TF_PARAM_TAU: p.tau = v; break;
@@ -846,6 +1020,60 @@ TF_API int tf_dbg_warp(tf_handle* h, const float* I0, const float* I1, const flo
     if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_warp: %s", hipGetErrorString(e));
     if ((rc = dbg_down(h, I1wx, dwx.p, g)) || (rc = dbg_down(h, I1wy, dwy.p, g)) || (rc = dbg_down(h, rho_c, drho.p, g))) return rc;
     return TF_OK;
+}
+
+TF_API int tf_dbg_df_blur(tf_handle* h, const float* src, int w, int hgt, float* dst)
+{
+    if (!h || !src || !dst || w < 1 || hgt < 1) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    const Geom g = make_geom(w, hgt);
+    DBuf a, b;
+    int rc;
+    if ((rc = dbg_up(h, a, src, g)) || (rc = dbg_up(h, b, nullptr, g))) return rc;
+    float k0, k1;
+    df_gauss3(h->DP.sigma > 0 ? h->DP.sigma : 0.6f, &k0, &k1);
+    hipLaunchKernelGGL(k_df_blur, grid64x4(g, 1), dim3(256), 0, h->stream, a.p, b.p, g, k0, k1);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_df_blur: %s", hipGetErrorString(e));
+    return dbg_down(h, dst, b.p, g);
+}
+
+TF_API int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v)
+{
+    if (!h || !I0 || !I1 || !u || !v || w < 1 || hgt < 1) return TF_ERR_INVALID_ARG;
+    if (h->P.algo != TF_ALGO_DEEPFLOW) return fail(h, TF_ERR_INVALID_ARG, "tf_dbg_df_refine needs a handle from tf_create_deepflow");
+    HIPC(h, hipSetDevice(h->dev));
+    const Geom g = make_geom(w, hgt);
+    float* fr = nullptr;
+    HIPC(h, hipMalloc(&fr, 2 * (size_t)g.plane * sizeof(float)));
+    DBuf keep; keep.p = fr;
+    HIPC(h, hipMemsetAsync(fr, 0, 2 * (size_t)g.plane * sizeof(float), h->stream));
+    HIPC(h, hipMemcpy2DAsync(fr, (size_t)g.pitch * 4, I0, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipMemcpy2DAsync(fr + g.plane, (size_t)g.pitch * 4, I1, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream));
+    float* planes = nullptr;
+    HIPC(h, hipMalloc(&planes, 21 * (size_t)g.plane * sizeof(float)));
+    DBuf keep2; keep2.p = planes;
+    HIPC(h, hipMemsetAsync(planes, 0, 21 * (size_t)g.plane * sizeof(float), h->stream));
+    const DfBufs saved = h->df;
+    {
+        float* p = planes;
+        DfBufs& d = h->df;
+        float** slots[] = {&d.avg, &d.Iz, &d.Ix, &d.Iy, &d.Ixx, &d.Ixy, &d.Iyy, &d.Ixz, &d.Iyz, &d.A11, &d.A12, &d.A22, &d.b1, &d.b2, &d.wg,
+                           &d.du, &d.dv, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
+        for (auto s_ : slots) { *s_ = p; p += g.plane; }
+    }
+    hipError_t e = hipMemcpy2DAsync(h->df.Wu[0], (size_t)g.pitch * 4, u, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(h->df.Wv[0], (size_t)g.pitch * 4, v, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        df_refine_level(h, fr, 0, 1, g, 0, 1, h->stream);
+        e = hipStreamSynchronize(h->stream);
+    }
+    int rc = TF_OK;
+    if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "deepflow refine: %s", hipGetErrorString(e));
+    if (!rc) rc = dbg_down(h, u, h->df.avg, g);
+    if (!rc) rc = dbg_down(h, v, h->df.Iz, g);
+    h->df = saved;
+    return rc;
 }
 
 TF_API int tf_dbg_median(tf_handle* h, const float* src, int w, int hgt, int ksize, float* dst)

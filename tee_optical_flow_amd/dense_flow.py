@@ -35,8 +35,25 @@ class DenseFlow:
                 "OuterIterations": "outer_iterations", "ScaleStep": "scale_step", "Gamma": "gamma",
                 "MedianFiltering": "median_filtering", "UseInitialFlow": "use_initial_flow"}
 
-    def __init__(self, device_id=0, max_batch=128, **params):
+    def __init__(self, device_id=0, max_batch=128, algo="TVL1", **params):
         self._L = _lib.load()
+        self.algo = algo
+        if algo == "deepflow":
+            dp = _lib.TfDeepflowParams()
+            _lib.check(self._L.tf_default_deepflow_params(C.byref(dp)), None, "tf_default_deepflow_params")
+            dp.max_batch = int(max_batch)
+            for k, v in params.items():
+                if not hasattr(dp, k):
+                    raise OpticalFlowCalculationError(f"unknown DeepFlow parameter {k!r}")
+                setattr(dp, k, v)
+            h = C.c_void_p()
+            _lib.check(self._L.tf_create_deepflow(C.byref(dp), int(device_id), C.byref(h)), None, "tf_create_deepflow")
+            self._h = h
+            self.device_id = int(device_id)
+            self.last_stats = None
+            return
+        if algo != "TVL1":
+            raise OpticalFlowCalculationError("OF_algo only supports deepflow or TVL1")
         p = _lib.TfParams()
         _lib.check(self._L.tf_default_params(C.byref(p)), None, "tf_default_params")
         p.max_batch = int(max_batch)
@@ -165,6 +182,11 @@ class DenseFlow:
                                               C.c_void_p(dflow_ptr), C.byref(st)), self._h, "tf_calc_seq_device")
         self._finish(st)
         return self.last_stats
+
+
+def createOptFlow_DeepFlow(device_id=0, **kw):
+    """Name-compatible factory for cv2.optflow.createOptFlow_DeepFlow() (reference :568)."""
+    return DenseFlow(device_id=device_id, algo="deepflow", **kw)
 
 
 def createOptFlow_DualTVL1(device_id=0, **kw):

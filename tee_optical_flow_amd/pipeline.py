@@ -30,7 +30,7 @@ def make_flow_model(OF_algo="TVL1", config=None, device_id=0):
         m.setLambda(config.lambda_value)
         return m
     if OF_algo == "deepflow":
-        raise OpticalFlowCalculationError("OF_algo='deepflow' is not implemented by the MI355X engine yet (SURVEY.md row a6)")
+        return DenseFlow(device_id=device_id, algo="deepflow")      # reference :568, all-default DeepFlow
     raise OpticalFlowCalculationError("OF_algo only supports deepflow or TVL1")
 
 

@@ -1,0 +1,102 @@
+"""DeepFlow path (BASELINE config 4) on the GPU against oracle/deepflow_oracle.c: bit-exact.
+(The oracle itself is a from-memory restatement of OpenCV's OpticalFlowDeepFlow / VariationalRefinement: parity with real
+OpenCV is UNPINNED -- see the oracle's header.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def deep():
+    import tee_optical_flow_amd as T
+    e = T.createOptFlow_DeepFlow()
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (30, 27), (1, 40), (3, 2)])
+def test_blur_bit_exact(deep, oracle, shape):
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    src = np.random.default_rng(0).uniform(0, 255, (h, w)).astype(np.float32)
+    ref = oracle.deepflow_gauss_blur3(src, 0.6)
+    out = np.empty_like(src)
+    _lib.check(L.tf_dbg_df_blur(deep._h, _ptr(src), w, h, _ptr(out)), deep._h)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("shape,amp", [((64, 64), 1.0), ((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5)])
+def test_variational_refinement_bit_exact(deep, oracle, shape, amp):
+    """One cv::VariationalRefinement::calcUV (warp, 8 derivative planes, 5 x [data term, smoothness, 25 red-black SOR sweeps])."""
+    from scipy import ndimage
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(1)
+    I0 = ndimage.gaussian_filter(rng.uniform(0, 255, (h, w)), 1.5).astype(np.float32)
+    I1 = ndimage.shift(I0, (0.7, -1.2), order=1, mode="nearest").astype(np.float32)
+    u = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
+    v = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
+    ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
+    gu, gv = u.copy(), v.copy()
+    _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    assert np.array_equal(gu, ru), f"u: {np.sum(gu != ru)} differ, max {np.abs(gu - ru).max()}"
+    assert np.array_equal(gv, rv)
+
+
+@pytest.mark.parametrize("seed,H,W", [(0, 96, 96), (1, 120, 160), (2, 64, 200)])
+def test_deepflow_pair_matches_oracle(deep, oracle, seed, H, W):
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, truth = speckle_pair(seed, H, W)
+    ref, nl = oracle.deepflow_calc(I0, I1, return_levels=True)
+    out = deep.calc(I0, I1, None)
+    assert out.shape == (H, W, 2) and out.dtype == np.float32
+    assert deep.last_stats["nscales_used"] == nl
+    e = np.sqrt(((out - ref) ** 2).sum(-1))
+    assert e.mean() <= 1e-3 and e.max() <= 1e-2        # north_star tolerance ...
+    assert np.array_equal(out, ref)                     # ... and in fact bit-exact
+    assert np.sqrt(((out - truth) ** 2).sum(-1))[12:-12, 12:-12].mean() < 0.1
+
+
+def test_deepflow_512_config4(deep, oracle):
+    """BASELINE.json configs[3]: OF_algo='deepflow', one 512x512 pair, all defaults (60 pyramid levels)."""
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, truth = speckle_pair(0, 512, 512)
+    ref, nl = oracle.deepflow_calc(I0, I1, return_levels=True)
+    out = deep.calc(I0, I1, None)
+    assert nl == 60 and deep.last_stats["nscales_used"] == 60
+    assert np.array_equal(out, ref)
+
+
+def test_deepflow_batch_and_sequence(deep, oracle):
+    from tee_optical_flow_amd.synth import speckle_pairs, speckle_sequence
+    I0s, I1s = speckle_pairs(range(10, 14), 72, 80)
+    flows = deep.calc_pairs(I0s, I1s)
+    for b in range(4):
+        assert np.array_equal(flows[b], oracle.deepflow_calc(I0s[b], I1s[b])), f"pair {b}"
+    fr = speckle_sequence(5, 4, 64, 72)
+    fs = deep.calc_batch(fr, scale=1.5)
+    for i in range(3):
+        assert np.array_equal(fs[i], oracle.deepflow_calc(fr[i], fr[i + 1]) * np.float32(1.5))
+
+
+def test_deepflow_identical_frames_zero_and_errors(deep):
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, _, _ = speckle_pair(3, 80, 80)
+    assert np.all(deep.calc(I0, I0, None) == 0.0)
+    with pytest.raises(T.OpticalFlowCalculationError):
+        deep.setLambda(0.1)                              # cv2's DeepFlow object has no setters either
+    with pytest.raises(T.OpticalFlowCalculationError):
+        T.DenseFlow(algo="farneback")
+    m = __import__("tee_optical_flow_amd.pipeline", fromlist=["make_flow_model"]).make_flow_model("deepflow")
+    assert m.algo == "deepflow"
+    m.close()
