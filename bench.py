@@ -43,20 +43,21 @@ def make_inputs(seeds, H, W):
     return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
 
 
-def cpu_baseline(I0s, I1s, n_sample):
+def cpu_baseline(I0s, I1s, n_sample, algo="TVL1"):
     """Oracle (CPU restatement, NOT OpenCV) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     threads = O.effective_cpus()
     O.set_num_threads(threads)
-    O.tvl1_calc(I0s[0], I1s[0])  # warm-up
+    calc = O.tvl1_calc if algo == "TVL1" else O.deepflow_calc
+    calc(I0s[0], I1s[0])  # warm-up
     flows = []
     t0 = time.perf_counter()
     for i in range(n_sample):
-        flows.append(O.tvl1_calc(I0s[i], I1s[i]))
+        flows.append(calc(I0s[i], I1s[i]))
     dt = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
             "sample": f"{n_sample} of the benchmark's 512x512 pairs (seeds 0..{n_sample - 1}), 1 warm-up, "
-                      f"oracle/tvl1_oracle.c with {threads} OpenMP threads; restatement, not OpenCV"}, flows
+                      f"oracle/{'tvl1' if algo == 'TVL1' else 'deepflow'}_oracle.c with {threads} OpenMP threads; restatement, not OpenCV"}, flows
 
 
 def main():
@@ -69,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket tvl1_iter launches with HIP events")
+    ap.add_argument("--algo", default="TVL1", choices=["TVL1", "deepflow"], help="BASELINE configs[1..2] (TVL1, default) or configs[3] (deepflow)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
@@ -105,7 +107,7 @@ def main():
     flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)]
     gdev = dev if a.backend == "nccl" else torch.device("cpu")
     gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
-    eng = T.DenseFlow(device_id=local_rank, max_batch=B)
+    eng = T.DenseFlow(device_id=local_rank, max_batch=B, algo=a.algo)
     # the engine runs on its own non-blocking HIP stream (its per-launch events are recorded there); every call is
     # host-synchronous, so torch-side consumers (the RCCL all-gather) may start right after it returns
     p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
@@ -154,7 +156,7 @@ def main():
         dt = float(t.item())
     # Roofline leg: the SAME K steps again with every tvl1_iter launch bracketed by a HIP event pair on the engine's
     # stream.  Kept out of the timed region above because ~1200 event records per step cost ~8% of a step.
-    if not a.no_profile:
+    if not a.no_profile and a.algo == "TVL1":
         eng.set_profile(1)
         for k in range(a.steps):
             st = step(a.warmup + a.steps + k)
@@ -178,29 +180,40 @@ def main():
                     traffic = json.load(f).get("tvl1_iter_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
-        out = {
-            "metric": "frame-pairs/sec @512x512 DualTVL1", "value": pairs / dt, "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
-                                   "configs[2] per-GPU shard), speckle-warp v1 seeds rank*B..; DualTVL1 all defaults, lambda 0.15, "
-                                   "5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; inputs resident in HBM; "
-                                   + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
-                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_iter2_rows (tvl1_iter, two inner iterations per launch)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        if a.algo == "TVL1":
+            ROOF = {"bound": "hbm", "kernel": "k_iter2_rows (tvl1_iter, two inner iterations per launch)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "launches": acc["iter_launches"], "bytes_per_px_iteration": 60,
                          "note": "achieved = executed pair-iterations x px x 60 B (the single-iteration kernel's compulsory traffic) / summed launch "
                                  "time; the launched kernel fuses two iterations, so its real HBM traffic (`traffic`, PMC) is about half of that "
                                  "and the kernel is bound by fp32/fp64 VALU issue (see DESIGN.md section 4)",
-                         "measured_on": f"{a.steps} instrumented repeats of the timed steps (one HIP event pair per launch, engine stream)"},
+                         "measured_on": f"{a.steps} instrumented repeats of the timed steps (one HIP event pair per launch, engine stream)"}
+        else:
+            whole = acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None
+            ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<2> (red-black SOR, 2 sweeps per launch; ~86% of device time)",
+                    "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (whole / HBM_PEAK_GBS) if whole else None, "traffic": None,
+                    "note": "whole-solve figure: algorithmic bytes of all DeepFlow kernels (one colour per launch SOR accounting, "
+                            "df_account_bytes) / device time; per-launch event instrumentation exists for tvl1_iter only"}
+        out = {
+            "metric": "frame-pairs/sec @512x512 " + ("DualTVL1" if a.algo == "TVL1" else "DeepFlow"), "value": pairs / dt, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
+                                   "configs[2] per-GPU shard), speckle-warp v1 seeds rank*B..; "
+                                   + ("DualTVL1 all defaults, lambda 0.15, 5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; "
+                                      if a.algo == "TVL1" else
+                                      "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
+                                   + "inputs resident in HBM; "
+                                   + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
+                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}"},
+            "roofline": ROOF,
             "executed_inner_iterations_per_pair": acc["inner"] / (B * a.steps),
             "executed_outer_iterations_per_pair": acc["outer"] / (B * a.steps),
             "whole_solve_algorithmic_GBps": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
         }
         # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
-        lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1)
+        lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1, algo=a.algo)
         f1 = torch.empty((1, H, W, 2), dtype=torch.float32, device=dev)
         for _ in range(3):
             lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
@@ -213,7 +226,7 @@ def main():
         lat_eng.close()
         if world == 1 and not a.no_cpu_baseline:
             n = min(a.cpu_sample, B)
-            cb, ref = cpu_baseline(I0s, I1s, n)
+            cb, ref = cpu_baseline(I0s, I1s, n, a.algo)
             out["cpu_baseline"] = cb
             last = a.warmup + a.steps - 1 + (0 if a.no_profile else a.steps)
             got = flows[last & 1][:n].cpu().numpy()

@@ -80,6 +80,7 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int sor_fuse = 2;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 2 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
     int min_rows_work = 4096;    // rows*pairs below which the tile kernel is used (tiny launches / single-pair latency)
@@ -514,11 +515,11 @@ int df_ensure_alloc(tf_handle* h, int H, int W, int B)
     HIPC(h, hipMalloc(&h->dpyr_base, total * sizeof(float)));
     HIPC(h, hipMalloc(&h->dtmp, F * (size_t)h->dlv[0].plane * sizeof(float)));
     const size_t pl = (size_t)h->dlv[0].plane * cap;
-    HIPC(h, hipMalloc(&h->dplanes, 21 * pl * sizeof(float)));
+    HIPC(h, hipMalloc(&h->dplanes, 23 * pl * sizeof(float)));
     float* p = h->dplanes;
     DfBufs& d = h->df;
     float** slots[] = {&d.avg, &d.Iz, &d.Ix, &d.Iy, &d.Ixx, &d.Ixy, &d.Iyy, &d.Ixz, &d.Iyz, &d.A11, &d.A12, &d.A22, &d.b1, &d.b2, &d.wg,
-                       &d.du, &d.dv, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
+                       &d.du, &d.dv, &d.du2, &d.dv2, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
     for (auto s_ : slots) { *s_ = p; p += pl; }
     h->dH = H; h->dW = W; h->dcap = want;
     return TF_OK;
@@ -543,22 +544,45 @@ void df_gauss3(float sigma, float* k0, float* k1)
     *k0 = (float)(t1 * inv); *k1 = (float)(t0 * inv);
 }
 
+template <int S>
+void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s)
+{
+    constexpr int RW = 64 + 4 * S, RH = 32 + 4 * S;
+    hipLaunchKernelGGL(k_df_sor_fused<S>, dim3((g.w + 63) / 64, (g.h + 31) / 32, B), dim3(256), (size_t)3 * RW * RH * sizeof(float), s, d, g, omega);
+}
+
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
 void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const Geom& g, int cur, int B, hipStream_t s)
 {
-    const DfBufs& d = h->df;
+    DfBufs d = h->df;
     const DfConst c = df_consts(h->DP);
     const dim3 gr = grid64x4(g, B), bl(256);
     const dim3 gsor(((g.w + 1) / 2 + 63) / 64, (g.h + 3) / 4, B);
     hipLaunchKernelGGL(k_df_warp, gr, bl, 0, s, pyr_l, off0, off1, d, cur, g);
     hipLaunchKernelGGL(k_df_grad1, gr, bl, 0, s, d, g);
     hipLaunchKernelGGL(k_df_grad2, gr, bl, 0, s, d, g);
+    const int fuse = h->sor_fuse < 0 ? 0 : (h->sor_fuse > 5 ? 5 : h->sor_fuse);
     for (int fp = 0; fp < h->DP.fixed_point_iterations; ++fp) {
         hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
         hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
-        for (int it = 0; it < h->DP.sor_iterations; ++it) {
-            hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 0, c.omega);
-            hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 1, c.omega);
+        int left = h->DP.sor_iterations;
+        while (left > 0) {
+            const int n = fuse > 0 ? (left < fuse ? left : fuse) : 0;
+            if (n == 0) {     // one colour per launch, in place
+                hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 0, c.omega);
+                hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 1, c.omega);
+                --left;
+                continue;
+            }
+            switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
+                case 1: launch_sor_fused<1>(d, g, B, c.omega, s); break;
+                case 2: launch_sor_fused<2>(d, g, B, c.omega, s); break;
+                case 3: launch_sor_fused<3>(d, g, B, c.omega, s); break;
+                case 4: launch_sor_fused<4>(d, g, B, c.omega, s); break;
+                default: launch_sor_fused<5>(d, g, B, c.omega, s); break;
+            }
+            std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
+            left -= n;
         }
     }
     hipLaunchKernelGGL(k_df_sum, gr, bl, 0, s, d, cur, g);
@@ -895,6 +919,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
+    else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
@@ -1051,15 +1076,15 @@ TF_API int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int 
     HIPC(h, hipMemcpy2DAsync(fr, (size_t)g.pitch * 4, I0, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream));
     HIPC(h, hipMemcpy2DAsync(fr + g.plane, (size_t)g.pitch * 4, I1, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream));
     float* planes = nullptr;
-    HIPC(h, hipMalloc(&planes, 21 * (size_t)g.plane * sizeof(float)));
+    HIPC(h, hipMalloc(&planes, 23 * (size_t)g.plane * sizeof(float)));
     DBuf keep2; keep2.p = planes;
-    HIPC(h, hipMemsetAsync(planes, 0, 21 * (size_t)g.plane * sizeof(float), h->stream));
+    HIPC(h, hipMemsetAsync(planes, 0, 23 * (size_t)g.plane * sizeof(float), h->stream));
     const DfBufs saved = h->df;
     {
         float* p = planes;
         DfBufs& d = h->df;
         float** slots[] = {&d.avg, &d.Iz, &d.Ix, &d.Iy, &d.Ixx, &d.Ixy, &d.Iyy, &d.Ixz, &d.Iyz, &d.A11, &d.A12, &d.A22, &d.b1, &d.b2, &d.wg,
-                           &d.du, &d.dv, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
+                           &d.du, &d.dv, &d.du2, &d.dv2, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
         for (auto s_ : slots) { *s_ = p; p += g.plane; }
     }
     hipError_t e = hipMemcpy2DAsync(h->df.Wu[0], (size_t)g.pitch * 4, u, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream);

@@ -16,6 +16,7 @@ struct DfBufs {
     float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz;   // image derivative planes of the current level
     float *A11, *A12, *A22, *b1, *b2, *wg;                      // linear system of the current fixed-point iteration
     float *du, *dv;                                             // flow increment
+    float *du2, *dv2;                                           // second copy: the fused SOR kernel reads (du,dv), writes (du2,dv2)
     float *Wu[2], *Wv[2];                                       // flow entering the level (ping-pong across levels)
 };
 
@@ -197,6 +198,93 @@ __global__ __launch_bounds__(256) void k_df_sor(DfBufs d, Geom g, int color, flo
     du += omega * ((sigmaU + d.b1[i] - dv * a12) / d.A11[i] - du);
     dv += omega * ((sigmaV + d.b2[i] - du * a12) / d.A22[i] - dv);
     d.du[i] = du; d.dv[i] = dv;
+}
+
+// S complete red-black sweeps per launch on a 64x32 tile with a halo of 2S pixels kept in LDS (du, dv and the weights;
+// the five system coefficients of every pixel a thread owns stay in its registers).  A half-sweep only moves information one
+// pixel, so after 2S half-sweeps everything farther than 2S-1 pixels from the staged region's edge is exactly what the
+// one-colour-per-launch form (k_df_sor) computes; only the tile is written back -- to the second (du2, dv2) copy, because
+// neighbouring tiles still read this tile's (du, dv) as their halo.  HBM traffic per sweep drops ~3x at S = 2.
+// Each thread owns NS "slots" (row, column pair); a slot holds one red and one black pixel, so in every half-sweep all
+// lanes have work (no idle colour), and the slot's geometry flags are computed once.
+template <int S>
+__global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float omega)
+{
+    constexpr int HL = 2 * S, TW = 64, TH = 32, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sdu = smem;
+    float* sdv = sdu + RW * RH;
+    float* swg = sdv + RW * RH;
+    const int b = blockIdx.z, x0 = blockIdx.x * TW - HL, y0 = blockIdx.y * TH - HL;
+    const int W = g.w, H = g.h, pitch = g.pitch;
+    const size_t po = (size_t)b * g.splane;
+    // per slot and colour c (0 = (x+y) even): LDS index, flags, coefficients
+    int pidx[2][NS];
+    unsigned flg[2][NS];        // bit0 update allowed, bit1 has left, bit2 has right, bit3 has up, bit4 has down, bit5 write back
+    float a11[2][NS], a12[2][NS], a22[2][NS], b1[2][NS], b2[2][NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int q = threadIdx.x + k * 256;
+        const int ry = q / HW, qx = q - ry * HW;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int rx = 2 * qx + ((c + x0 + y0 + ry) & 1);
+            const int gx = x0 + rx, gy = y0 + ry;
+            const int p = ry * RW + rx;
+            const bool inimg = q < NSLOT && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            float du = 0.f, dv = 0.f, w = 0.f;
+            a11[c][k] = a22[c][k] = 1.f; a12[c][k] = b1[c][k] = b2[c][k] = 0.f;
+            if (inimg) {
+                const size_t i = po + (size_t)gy * pitch + gx;
+                du = d.du[i]; dv = d.dv[i]; w = d.wg[i];
+                a11[c][k] = d.A11[i]; a12[c][k] = d.A12[i]; a22[c][k] = d.A22[i]; b1[c][k] = d.b1[i]; b2[c][k] = d.b2[i];
+            }
+            if (q < NSLOT) { sdu[p] = du; sdv[p] = dv; swg[p] = w; }
+            // a pixel can be updated when each neighbour is either outside the image (no edge) or inside the staged region
+            const bool ok = inimg && (gx == 0 || rx > 0) && (gx == W - 1 || rx < RW - 1) && (gy == 0 || ry > 0) && (gy == H - 1 || ry < RH - 1);
+            const bool wb = inimg && rx >= HL && rx < HL + TW && ry >= HL && ry < HL + TH;
+            pidx[c][k] = p;
+            flg[c][k] = (ok ? 1u : 0u) | (gx > 0 ? 2u : 0u) | (gx < W - 1 ? 4u : 0u) | (gy > 0 ? 8u : 0u) | (gy < H - 1 ? 16u : 0u) | (wb ? 32u : 0u);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int sw = 0; sw < S; ++sw) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const unsigned f = flg[c][k];
+                if (f & 1u) {
+                    const int p = pidx[c][k];
+                    const float ws = swg[p];
+                    const float wl = (f & 2u) ? swg[p - 1] : 0.f, wu_ = (f & 8u) ? swg[p - RW] : 0.f;
+                    const float wr = (f & 4u) ? ws : 0.f, wd = (f & 16u) ? ws : 0.f;
+                    const float dul = (f & 2u) ? sdu[p - 1] : 0.f, dur = (f & 4u) ? sdu[p + 1] : 0.f;
+                    const float duu = (f & 8u) ? sdu[p - RW] : 0.f, dud = (f & 16u) ? sdu[p + RW] : 0.f;
+                    const float dvl = (f & 2u) ? sdv[p - 1] : 0.f, dvr = (f & 4u) ? sdv[p + 1] : 0.f;
+                    const float dvu = (f & 8u) ? sdv[p - RW] : 0.f, dvd = (f & 16u) ? sdv[p + RW] : 0.f;
+                    const float sigmaU = wl * dul + wr * dur + wu_ * duu + wd * dud;
+                    const float sigmaV = wl * dvl + wr * dvr + wu_ * dvu + wd * dvd;
+                    float du = sdu[p], dv = sdv[p];
+                    du += omega * ((sigmaU + b1[c][k] - dv * a12[c][k]) / a11[c][k] - du);
+                    dv += omega * ((sigmaV + b2[c][k] - du * a12[c][k]) / a22[c][k] - dv);
+                    sdu[p] = du; sdv[p] = dv;
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (flg[c][k] & 32u) {
+                const int p = pidx[c][k];
+                const int ry = p / RW, rx = p - ry * RW;
+                const size_t i = po + (size_t)(y0 + ry) * pitch + (x0 + rx);
+                d.du2[i] = sdu[p]; d.dv2[i] = sdv[p];       // other tiles still read (du, dv) of this tile as their halo
+            }
 }
 
 // W + dW of this level -> flow of the next finer level (resize INTER_LINEAR to its size, times 1/downscaleFactor)
