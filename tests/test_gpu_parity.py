@@ -126,6 +126,33 @@ def test_every_iteration_kernel_form_end_to_end(oracle, variant, params):
     eng.close()
 
 
+def test_wide_image_uses_tile_kernel_and_matches(oracle):
+    """W > 1024 cannot use the full-width strip kernels: the 64x16-tile form takes over (same bits)."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pair
+    I0, I1, _ = speckle_pair(90, 48, 1100)
+    eng = T.DenseFlow(nscales=3)
+    eng.set_tuning("min_rows_work", 0)
+    out = eng.calc(I0, I1, None)
+    ref, ref_it, nl = oracle.tvl1_calc(I0, I1, oracle.default_params(nscales=3), return_iters=True)
+    assert np.array_equal(eng.last_iters()[0], ref_it[:nl]) and np.array_equal(out, ref)
+    eng.close()
+
+
+def test_tiny_images(oracle):
+    import tee_optical_flow_amd as T
+    eng = T.DenseFlow()
+    rng = np.random.default_rng(3)
+    for shape in [(8, 8), (17, 5), (16, 16), (1, 33)]:
+        I0 = rng.integers(0, 256, shape, dtype=np.uint8)
+        I1 = rng.integers(0, 256, shape, dtype=np.uint8)
+        out = eng.calc(I0, I1, None)
+        ref, ref_it, nl = oracle.tvl1_calc(I0, I1, return_iters=True)
+        assert eng.last_stats["nscales_used"] == nl
+        assert np.array_equal(out, ref), shape
+    eng.close()
+
+
 def test_symmetries(engine):
     """SURVEY.md 8c item 3 (behavioural KATs on the GPU path itself): transpose swaps (u,v)."""
     from tee_optical_flow_amd.synth import speckle_pair
