@@ -157,6 +157,7 @@ def main():
     # Roofline leg: the SAME K steps again with every tvl1_iter launch bracketed by a HIP event pair on the engine's
     # stream.  Kept out of the timed region above because ~1200 event records per step cost ~8% of a step.
     if not a.no_profile and a.algo == "TVL1":
+        eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include the other lane's kernels
         eng.set_profile(1)
         for k in range(a.steps):
             st = step(a.warmup + a.steps + k)
@@ -164,6 +165,7 @@ def main():
         drain()
         torch.cuda.synchronize(dev)
         eng.set_profile(0)
+        eng.set_tuning("lanes", 2)
 
     out = None
     if rank == 0:
@@ -188,7 +190,7 @@ def main():
                          "note": "achieved = executed pair-iterations x px x 60 B (the single-iteration kernel's compulsory traffic) / summed launch "
                                  "time; the launched kernel fuses two iterations, so its real HBM traffic (`traffic`, PMC) is about half of that "
                                  "and the kernel is bound by fp32/fp64 VALU issue (see DESIGN.md section 4)",
-                         "measured_on": f"{a.steps} instrumented repeats of the timed steps (one HIP event pair per launch, engine stream)"}
+                         "measured_on": f"{a.steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
         else:
             whole = acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None
             ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<2> (red-black SOR, 2 sweeps per launch; ~86% of device time)",

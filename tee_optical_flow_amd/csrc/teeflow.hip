@@ -21,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define TF_API extern "C" __attribute__((visibility("default")))
@@ -80,6 +81,9 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
+                                 // while one lane runs the thin tail of a stage, the other fills the GPU (+6 % measured; 4 lanes lose)
+    tf_handle* twin = nullptr; bool is_twin = false;
     int sor_fuse = 2;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 2 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
@@ -87,6 +91,10 @@ struct tf_handle {
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
 };
+
+TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out);
+TF_API int tf_create_deepflow(const tf_deepflow_params* p, int device_id, tf_handle** out);
+TF_API const char* tf_last_error(tf_handle* h);
 
 namespace {
 
@@ -718,6 +726,49 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     return TF_OK;
 }
 
+// Entry used by the C ABI: optionally splits the batch over two lanes (this handle + a twin with its own stream / buffers)
+int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
+               float* flow_out, bool device, tf_stats* st)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (h->lanes < 2 || h->is_twin || n_pairs < 32 || !in0 || !flow_out || (mode == MODE_PAIRS && !in1) || H < 1 || W < 1 || h->stream != h->own_stream)
+        return calc_common(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
+    if (!h->twin) {
+        int rc = h->P.algo == TF_ALGO_DEEPFLOW ? tf_create_deepflow(&h->DP, h->dev, &h->twin) : tf_create(&h->P, h->dev, &h->twin);
+        if (rc) return fail(h, rc, "creating the second lane failed: %s", tf_last_error(nullptr));
+        h->twin->is_twin = true;
+    }
+    tf_handle* t = h->twin;
+    t->P = h->P; t->DP = h->DP; t->profile = h->profile;
+    t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
+    t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
+    const size_t fpx = (size_t)H * W;
+    const int nA = n_pairs / 2, nB = n_pairs - nA;
+    const uint8_t* b0 = mode == MODE_SEQ ? in0 + (size_t)nA * fpx : in0 + (size_t)nA * fpx;      // SEQ: frames nA..n_pairs (1-frame overlap)
+    const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)nA * fpx;
+    tf_stats sa, sb;
+    int rcB = TF_OK;
+    std::thread lane([&] { rcB = calc_common(t, mode, b0, b1, nB, H, W, scale, flow_out + (size_t)nA * fpx * 2, device, &sb); });
+    const int rcA = calc_common(h, mode, in0, in1, nA, H, W, scale, flow_out, device, &sa);
+    lane.join();
+    if (rcA) return rcA;
+    if (rcB) return fail(h, rcB, "%s", t->err.c_str());
+    h->last_iters.insert(h->last_iters.end(), t->last_iters.begin(), t->last_iters.end());
+    h->last_pairs = n_pairs;
+    if (st) {
+        *st = sa;
+        st->n_pairs = n_pairs;
+        st->ms_total = sa.ms_total > sb.ms_total ? sa.ms_total : sb.ms_total;
+        st->ms_h2d = sa.ms_h2d > sb.ms_h2d ? sa.ms_h2d : sb.ms_h2d;
+        st->ms_device = sa.ms_device > sb.ms_device ? sa.ms_device : sb.ms_device;
+        st->ms_d2h = sa.ms_d2h > sb.ms_d2h ? sa.ms_d2h : sb.ms_d2h;
+        st->iter_launches += sb.iter_launches; st->iter_pair_steps += sb.iter_pair_steps; st->iter_ms += sb.iter_ms;
+        st->iter_bytes += sb.iter_bytes; st->total_bytes += sb.total_bytes;
+        st->inner_iters_total += sb.inner_iters_total; st->outer_iters_total += sb.outer_iters_total;
+    }
+    return TF_OK;
+}
+
 // ---- small RAII device buffer for the tf_dbg_* hooks ---------------------------------------------
 struct DBuf {
     float* p = nullptr;
@@ -843,6 +894,7 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
 TF_API void tf_destroy(tf_handle* h)
 {
     if (!h) return;
+    if (h->twin) { tf_destroy(h->twin); h->twin = nullptr; }
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_buffers(h);
@@ -919,6 +971,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
+    else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 2 ? 2 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
@@ -934,30 +987,30 @@ TF_API int tf_set_profile(tf_handle* h, int level)
 
 TF_API int tf_calc_pair(tf_handle* h, const uint8_t* I0, const uint8_t* I1, int H, int W, float* flow_out, tf_stats* st)
 {
-    return calc_common(h, MODE_PAIRS, I0, I1, 1, H, W, 1.0f, flow_out, false, st);
+    return calc_entry(h, MODE_PAIRS, I0, I1, 1, H, W, 1.0f, flow_out, false, st);
 }
 
 TF_API int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st)
 {
-    return calc_common(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, st);
+    return calc_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, st);
 }
 
 TF_API int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, tf_stats* st)
 {
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    return calc_common(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, false, st);
+    return calc_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, false, st);
 }
 
 TF_API int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W, float scale,
                                 float* dflow_out, tf_stats* st)
 {
-    return calc_common(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, true, st);
+    return calc_entry(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, true, st);
 }
 
 TF_API int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, tf_stats* st)
 {
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    return calc_common(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, st);
+    return calc_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, st);
 }
 
 TF_API int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written)

@@ -126,6 +126,30 @@ def test_every_iteration_kernel_form_end_to_end(oracle, variant, params):
     eng.close()
 
 
+def test_two_lane_split_of_large_batches(oracle):
+    """Batches of >= 32 pairs are split over two (handle, stream, host thread) lanes; results and per-pair iteration counts
+    must be those of the single-lane run (and of the oracle), in the caller's pair order; sequence mode overlaps one frame."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs, speckle_sequence
+    I0s, I1s = speckle_pairs(range(200, 237), 48, 64)          # 37 pairs -> lanes of 18 and 19
+    eng = T.DenseFlow()
+    f2 = eng.calc_pairs(I0s, I1s)
+    it2 = eng.last_iters()
+    eng.set_tuning("lanes", 1)
+    f1 = eng.calc_pairs(I0s, I1s)
+    it1 = eng.last_iters()
+    assert np.array_equal(f1, f2) and np.array_equal(it1, it2) and it2.shape[0] == 37
+    for b in (0, 17, 18, 36):
+        ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], return_iters=True)
+        assert np.array_equal(f2[b], ref) and np.array_equal(it2[b], ref_it[:nl])
+    eng.set_tuning("lanes", 2)
+    fr = speckle_sequence(7, 40, 40, 48)                         # 39 pairs
+    fs = eng.calc_batch(fr)
+    for i in (0, 18, 19, 38):
+        assert np.array_equal(fs[i], oracle.tvl1_calc(fr[i], fr[i + 1])), i
+    eng.close()
+
+
 def test_wide_image_uses_tile_kernel_and_matches(oracle):
     """W > 1024 cannot use the full-width strip kernels: the 64x16-tile form takes over (same bits)."""
     import tee_optical_flow_amd as T
