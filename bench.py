@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket tvl1_iter launches with HIP events")
     ap.add_argument("--algo", default="TVL1", choices=["TVL1", "deepflow"], help="BASELINE configs[1..2] (TVL1, default) or configs[3] (deepflow)")
+    ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
@@ -108,6 +109,7 @@ def main():
     gdev = dev if a.backend == "nccl" else torch.device("cpu")
     gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
     eng = T.DenseFlow(device_id=local_rank, max_batch=B, algo=a.algo)
+    eng.set_tuning("lanes", a.lanes)
     # the engine runs on its own non-blocking HIP stream (its per-launch events are recorded there); every call is
     # host-synchronous, so torch-side consumers (the RCCL all-gather) may start right after it returns
     p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
@@ -165,7 +167,7 @@ def main():
         drain()
         torch.cuda.synchronize(dev)
         eng.set_profile(0)
-        eng.set_tuning("lanes", 2)
+        eng.set_tuning("lanes", a.lanes)
 
     out = None
     if rank == 0:
@@ -208,7 +210,7 @@ def main():
                                       "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
                                    + "inputs resident in HBM; "
                                    + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
-                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}"},
+                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}", "lanes_per_gpu": a.lanes},
             "roofline": ROOF,
             "executed_inner_iterations_per_pair": acc["inner"] / (B * a.steps),
             "executed_outer_iterations_per_pair": acc["outer"] / (B * a.steps),
