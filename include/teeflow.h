@@ -135,6 +135,12 @@ int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s,
 int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale,
                        float* dflow_out, tf_stats* st);
 
+/* Frame conditioning of the reference's loop, `img2uint8(rgb2gray(nparr[i]))` (calculate_optical_flow.py:588,
+ * optical_flow_utils.py:30-31), on the device: rgb uint8 [N][H][W][3] -> gray uint8 [N][H][W], normalised per frame.
+ * tf_calc_seq_rgb = condition + tf_calc_seq without the frames ever returning to the host (flow_out: [N-1][H][W][2]). */
+int tf_condition_frames(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t* gray_out);
+int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, tf_stats* st);
+
 /* Executed iteration counts of the last call: int32 [n_pairs][nscales_used][warps][2] = (inner, outer).
  * Returns the number of ints written (<= capacity) through *written. */
 int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written);

@@ -84,6 +84,7 @@ struct tf_handle {
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU (+6 % measured; 4 lanes lose)
     tf_handle* twin = nullptr; bool is_twin = false;
+    int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int sor_fuse = 2;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 2 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
@@ -252,11 +253,13 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
 }
 
 // launch one two-iteration tvl1_iter step (k_iter2_rows)
-void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
+void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int active_hint = 0)
 {
     const Geom& g = A.a.g;
     int R, QX, RY, threads;
-    strip_shape(h, g, B, &R, &QX, &RY, &threads, true);
+    // rows per strip follow the number of pairs known to be still iterating: the thin tail launches of a stage get many
+    // short strips (latency of a few steps) instead of a few long ones
+    strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
     const int LW = QX * 4 + 4;
     const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY);
@@ -325,6 +328,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
         int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
         bool stop = false;
+        int last_active = B;
         const unsigned seq0 = h->launch_seq;
         unsigned checked = seq0;
         for (int it = 0; it <= total && !stop; it += 2) {
@@ -349,10 +353,10 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
                 }
                 ProfEv& pe = h->prof_pool[h->prof_used++];
                 HIPC(h, hipEventRecord(pe.a, s));
-                launch_iter2(h, A2, B, s);
+                launch_iter2(h, A2, B, s, last_active);
                 HIPC(h, hipEventRecord(pe.b, s));
             } else {
-                launch_iter2(h, A2, B, s);
+                launch_iter2(h, A2, B, s, last_active);
             }
             ++h->iter_launches;
             utog_prev = utog; ptog_prev = ptog; pzero_prev = A2.a.pzero;
@@ -370,6 +374,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
                 }
                 ++checked;
                 if (v == 0) { stop = true; break; }
+                last_active = v;
             }
         }
         hipLaunchKernelGGL(k_stage_end2, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
@@ -971,6 +976,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lag") h->lag = value > 0 ? value : DEFAULT_LAG;
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
+    else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 2 ? 2 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
@@ -1011,6 +1017,65 @@ TF_API int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H
 {
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
     return calc_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, st);
+}
+
+namespace {
+// rgb (host) -> conditioned gray frames in a fresh device buffer (caller frees)
+int condition_to_device(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t** dgray_out)
+{
+    const size_t npx = (size_t)H * W;
+    uint8_t* drgb = nullptr; uint8_t* dgray = nullptr; u64* mm = nullptr;
+    HIPC(h, hipSetDevice(h->dev));
+    HIPC(h, hipMalloc(&drgb, (size_t)N * npx * 3));
+    hipError_t e = hipMalloc(&dgray, (size_t)N * npx);
+    if (e == hipSuccess) e = hipMalloc(&mm, (size_t)N * 2 * sizeof(u64));
+    std::vector<u64> init((size_t)N * 2);
+    for (int f = 0; f < N; ++f) { init[2 * f] = ~0ull; init[2 * f + 1] = 0ull; }
+    if (e == hipSuccess) e = hipMemcpyAsync(drgb, rgb, (size_t)N * npx * 3, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mm, init.data(), init.size() * sizeof(u64), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const int gx = (int)((npx + 255) / 256);
+        hipLaunchKernelGGL(k_cond_minmax, dim3(gx < 512 ? gx : 512, N), dim3(256), 0, h->stream, drgb, npx, mm);
+        hipLaunchKernelGGL(k_cond_norm, dim3(gx, N), dim3(256), 0, h->stream, drgb, npx, mm, dgray);
+        e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(drgb); (void)hipFree(mm);
+    if (e != hipSuccess) { (void)hipFree(dgray); return fail(h, TF_ERR_HIP, "frame conditioning: %s", hipGetErrorString(e)); }
+    *dgray_out = dgray;
+    return TF_OK;
+}
+}  // namespace
+
+TF_API int tf_condition_frames(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t* gray_out)
+{
+    if (!h || !rgb || !gray_out || N < 1 || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    uint8_t* dgray = nullptr;
+    int rc = condition_to_device(h, rgb, N, H, W, &dgray);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(gray_out, dgray, (size_t)N * H * W, hipMemcpyDeviceToHost);
+    (void)hipFree(dgray);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    return TF_OK;
+}
+
+TF_API int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, tf_stats* st)
+{
+    if (!h || !rgb || !flow_out || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    uint8_t* dgray = nullptr;
+    int rc = condition_to_device(h, rgb, N, H, W, &dgray);
+    if (rc) return rc;
+    float* dflow = nullptr;
+    const size_t fbytes = (size_t)(N - 1) * H * W * 2 * sizeof(float);
+    hipError_t e = hipMalloc(&dflow, fbytes);
+    if (e != hipSuccess) { (void)hipFree(dgray); return fail(h, TF_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    rc = calc_entry(h, MODE_SEQ, dgray, nullptr, N - 1, H, W, scale, dflow, true, st);
+    if (!rc) {
+        e = hipMemcpy(flow_out, dflow, fbytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dgray); (void)hipFree(dflow);
+    return rc;
 }
 
 TF_API int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written)

@@ -1118,3 +1118,53 @@ __global__ __launch_bounds__(256) void k_output(StateBufs sb, const PairCtl* __r
     float2 v = make_float2(sb.u1[uc][i] * scale, sb.u2[uc][i] * scale);
     reinterpret_cast<float2*>(out)[((size_t)b * g.h + y) * g.w + x] = v;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Frame conditioning on the device: img2uint8(rgb2gray(frame)) of the reference
+// (/root/reference/optical_flow/calculate_optical_flow.py:588, optical_flow_utils.py:30-31), per frame:
+//   g = (R/255)*0.2125 + (G/255)*0.7154 + (B/255)*0.0721   (float64, skimage.color.rgb2gray)
+//   u8 = rint(((g - min g) / max g) * 255)                  (the reference divides by max, NOT max - min)
+// Pass 1 reduces per-frame min / max of g (non-negative doubles order like their bit patterns, so integer atomics do);
+// pass 2 recomputes g and writes the byte.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double luma_f64(const uint8_t* p)
+{
+    return ((double)p[0] / 255.0) * 0.2125 + ((double)p[1] / 255.0) * 0.7154 + ((double)p[2] / 255.0) * 0.0721;
+}
+
+__global__ __launch_bounds__(256) void k_cond_minmax(const uint8_t* __restrict__ rgb, size_t npx, u64* __restrict__ mm /* [F][2] */)
+{
+    __shared__ u64 smin[4], smax[4];
+    const int f = blockIdx.y;
+    const uint8_t* src = rgb + (size_t)f * npx * 3;
+    u64 lo = ~0ull, hi = 0ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) {
+        const u64 b = (u64)__double_as_longlong(luma_f64(src + i * 3));
+        lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { lo = smin[w] < lo ? smin[w] : lo; hi = smax[w] > hi ? smax[w] : hi; }
+        lo = smin[0] < lo ? smin[0] : lo; hi = smax[0] > hi ? smax[0] : hi;
+        atomicMin(&mm[2 * f], lo);
+        atomicMax(&mm[2 * f + 1], hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cond_norm(const uint8_t* __restrict__ rgb, size_t npx, const u64* __restrict__ mm, uint8_t* __restrict__ out)
+{
+    const int f = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const double mn = __longlong_as_double((long long)mm[2 * f]), mx = __longlong_as_double((long long)mm[2 * f + 1]);
+    const double g = luma_f64(rgb + ((size_t)f * npx + i) * 3);
+    double v = rint(((g - mn) / mx) * 255.0);
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);          // NaN (all-black frame: 0/0) falls through to 0 below
+    out[(size_t)f * npx + i] = (uint8_t)(v == v ? (int)v : 0);
+}

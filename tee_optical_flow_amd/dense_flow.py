@@ -154,6 +154,29 @@ class DenseFlow:
         self._finish(st)
         return out
 
+    def condition_frames(self, nparr):
+        """Device version of frames.condition_frames: uint8 [N,H,W,3] -> uint8 [N,H,W] = img2uint8(rgb2gray(frame)) per frame."""
+        nparr = _u8_image_stack(nparr, "nparr", 4)
+        if nparr.shape[3] != 3:
+            raise OpticalFlowCalculationError(f"nparr must be [N,H,W,3], got {nparr.shape}")
+        N, H, W, _ = nparr.shape
+        out = np.empty((N, H, W), np.uint8)
+        _lib.check(self._L.tf_condition_frames(self._h, nparr.ctypes.data, N, H, W, out.ctypes.data), self._h, "tf_condition_frames")
+        return out
+
+    def calc_study(self, nparr, scale=1.0):
+        """RGB study uint8 [N,H,W,3] -> float32 [N-1,H,W,2]: conditioning and all pair solves stay on the device."""
+        nparr = _u8_image_stack(nparr, "nparr", 4)
+        if nparr.shape[3] != 3 or nparr.shape[0] < 2:
+            raise OpticalFlowCalculationError(f"nparr must be [N>=2,H,W,3], got {nparr.shape}")
+        N, H, W, _ = nparr.shape
+        out = np.empty((N - 1, H, W, 2), np.float32)
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_seq_rgb(self._h, nparr.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(st)),
+                   self._h, "tf_calc_seq_rgb")
+        self._finish(st)
+        return out
+
     def calc_pairs(self, I0s, I1s):
         """B independent pairs: uint8 [B,H,W] x2 -> float32 [B,H,W,2]."""
         I0s = _u8_image_stack(I0s, "I0s", 3)

@@ -61,13 +61,16 @@ def _compensate(flow, mask_dict, bkgd_comp):
     return flow - background
 
 
-def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conversion_factor=1.0):
+def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conversion_factor=1.0, nparr_rgb=None):
     """Reference :584-600 for already-conditioned uint8 frames [N,H,W]: N-1 flows, last one duplicated, scaled.
     All N-1 pairs are solved by ONE batched call (tf_calc_seq); background compensation (per pair) and the unit
     scale are applied in the reference's order: (flow - background) * conversion_factor."""
     if bkgd_comp not in ("WASE", "none"):
         raise OpticalFlowCalculationError(f"bkgd_comp value must be [WASE, none], got {bkgd_comp}!")
-    flows = OF_model.calc_batch(frames_u8)                       # float32 [N-1,H,W,2]
+    if nparr_rgb is not None and hasattr(OF_model, "calc_study"):
+        flows = OF_model.calc_study(nparr_rgb)                   # conditioning (:588) + all pairs on the device
+    else:
+        flows = OF_model.calc_batch(frames_u8)                   # float32 [N-1,H,W,2]
     if bkgd_comp == "WASE":
         flows = np.stack([_compensate(flows[i], mask_dict, "WASE") for i in range(flows.shape[0])])
     flows = np.concatenate([flows, flows[-1:]], axis=0)          # copy last optical flow (:599)
@@ -113,8 +116,10 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
     own = flow_model is None
     model = make_flow_model(OF_algo, config) if own else flow_model
     try:
-        frames = condition_frames(nparr)
-        flow_arr = flow_for_study(frames, model, mask_dict, bkgd_comp, conversion_factor)
+        on_device = hasattr(model, "calc_study") and nparr.ndim == 4 and nparr.shape[3] == 3 and nparr.dtype == np.uint8
+        frames = None if on_device else condition_frames(nparr)
+        flow_arr = flow_for_study(frames, model, mask_dict, bkgd_comp, conversion_factor,
+                                  nparr_rgb=np.ascontiguousarray(nparr) if on_device else None)
     finally:
         if own:
             model.close()

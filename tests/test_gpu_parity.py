@@ -199,3 +199,33 @@ def test_error_behaviour(engine):
     assert engine.getGamma() == 0.0
     engine.setLambda(0.15)
     assert engine.getLambda() == 0.15
+
+
+def test_device_frame_conditioning_matches_reference_fixture(engine):
+    """Row a1/f4: img2uint8(rgb2gray(frame)) on the device == the reference's own output (fixture) and the host restatement."""
+    import os
+    from tee_optical_flow_amd.frames import condition_frames
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_host_side.npz"))
+    assert np.array_equal(engine.condition_frames(g["cond_in_rgb"][None])[0], g["cond_out_u8"])
+    assert np.array_equal(engine.condition_frames(g["cond_in_ramp"][None])[0], g["cond_out_ramp"])
+    rng = np.random.default_rng(5)
+    study = rng.integers(0, 256, (7, 96, 130, 3), dtype=np.uint8)
+    study[3] //= 4                      # a dark frame: per-frame normalisation
+    study[5, ..., :] = study[5, ..., :1]  # a grey frame
+    assert np.array_equal(engine.condition_frames(study), condition_frames(study))
+
+
+def test_study_from_rgb_on_device_equals_host_conditioned_path(engine, oracle):
+    from tee_optical_flow_amd.frames import condition_frames
+    from tee_optical_flow_amd.pipeline import process_video
+    from tee_optical_flow_amd.synth import speckle_sequence
+    gsq = speckle_sequence(11, 5, 64, 80)
+    nparr = np.repeat(gsq[..., None], 3, axis=3)
+    a = engine.calc_study(nparr, scale=1.5)
+    b = engine.calc_batch(condition_frames(nparr), scale=1.5)
+    assert np.array_equal(a, b)
+    md = {"pixel_spacing": 0.05, "frame_rate": 30.0, "R_wave_data_present": False, "R_times": None}
+    out = process_video(None, None, None, verbose=False, mode="otsu", no_saliency=True, nparr=nparr, metadata=md, flow_model=engine)
+    fr = condition_frames(nparr)
+    assert out.shape == (5, 64, 80, 2) and np.array_equal(out[3], out[4])
+    assert np.array_equal(out[0], oracle.tvl1_calc(fr[0], fr[1]) * (0.05 * 30.0))
