@@ -141,6 +141,20 @@ int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W
 int tf_condition_frames(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t* gray_out);
 int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, tf_stats* st);
 
+/* ---- radial / longitudinal projection + per-frame statistics of the reference's analysis step
+ *      (optical_flow/analysis.py:89-212: calculate_comp_magnitude, calc_bidirectional_hist), float64, on the device.
+ * tf_radlong_project: flow host float32 [N][H][W][2], centroids host float64 [N][2] = (row, col).  rad_out / long_out
+ *   (host float64 [N][H][W]) may be NULL.  minmax[4] = rad min, rad max, long min, long max over the whole arrays
+ *   (zeros included, as np.min/np.max); nonzero[2N] = per frame count of non-zero rad / long values.  The projections
+ *   stay resident for the two calls below (which: 0 = radial, 1 = longitudinal).
+ * tf_radlong_hist: np.histogram(frame[frame != 0], bins=nbins, range=(edges[0], edges[nbins])) per frame, RAW counts.
+ * tf_radlong_select: exact order statistics: values[n][j] = sorted(frame n's non-zero values)[ranks[n][j]] for up to 4
+ *   ranks per frame (rank < 0 = skip) -- what np.percentile interpolates between. */
+int tf_radlong_project(tf_handle* h, const float* flow, const double* centroids, int N, int H, int W,
+                       double* rad_out, double* long_out, double* minmax, long long* nonzero);
+int tf_radlong_hist(tf_handle* h, int which, const double* edges, int nbins, long long* freq_out);
+int tf_radlong_select(tf_handle* h, int which, const long long* ranks, double* values_out);
+
 /* Executed iteration counts of the last call: int32 [n_pairs][nscales_used][warps][2] = (inner, outer).
  * Returns the number of ints written (<= capacity) through *written. */
 int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written);

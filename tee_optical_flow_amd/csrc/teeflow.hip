@@ -12,6 +12,7 @@
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
 #include "teeflow_deepflow.hip.h"
+#include "teeflow_analysis.hip.h"
 #include "../../include/teeflow.h"
 
 #include <chrono>
@@ -77,6 +78,8 @@ struct tf_handle {
     float* dtmp = nullptr;                                          // unblurred level-0 frames
     float* dplanes = nullptr;                                       // 21 state planes x cap pairs
     DfBufs df = {};
+    // ---- analysis session (row f1) ----
+    double* an_rad = nullptr; double* an_lon = nullptr; int anN = 0, anH = 0, anW = 0;
     // tuning knobs (tf_set_tuning)
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
@@ -157,6 +160,7 @@ void free_buffers(tf_handle* h)
     F(h->ctl); F(h->errs); F(h->iters_dev);
     F(h->st_u8); F(h->st_flow);
     F(h->dpyr_base); F(h->dtmp); F(h->dplanes);
+    F(h->an_rad); F(h->an_lon); h->anN = 0;
     h->dnlev = h->dH = h->dW = h->dcap = 0;
     h->st_u8_bytes = h->st_flow_bytes = 0;
     h->H = h->W = h->cap = h->nlev = 0; h->iters_cap = 0;
@@ -1076,6 +1080,102 @@ TF_API int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W
     }
     (void)hipFree(dgray); (void)hipFree(dflow);
     return rc;
+}
+
+TF_API int tf_radlong_project(tf_handle* h, const float* flow, const double* centroids, int N, int H, int W,
+                              double* rad_out, double* long_out, double* minmax, long long* nonzero)
+{
+    if (!h || !flow || !centroids || !minmax || !nonzero || N < 1 || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    HIPC(h, hipSetDevice(h->dev));
+    const size_t npx = (size_t)H * W, tot = (size_t)N * npx;
+    if (h->an_rad) { (void)hipFree(h->an_rad); h->an_rad = nullptr; }
+    if (h->an_lon) { (void)hipFree(h->an_lon); h->an_lon = nullptr; }
+    h->anN = 0;
+    HIPC(h, hipMalloc(&h->an_rad, tot * sizeof(double)));
+    HIPC(h, hipMalloc(&h->an_lon, tot * sizeof(double)));
+    float* dflow = nullptr; double* dcent = nullptr; u64* mm = nullptr; unsigned long long* cnt = nullptr;
+    hipError_t e = hipMalloc(&dflow, tot * 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&dcent, (size_t)N * 2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&mm, 4 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc(&cnt, (size_t)N * 2 * sizeof(unsigned long long));
+    const u64 mm0[4] = {~0ull, 0ull, ~0ull, 0ull};
+    u64 mmh[4];
+    std::vector<unsigned long long> ch((size_t)N * 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(dflow, flow, tot * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dcent, centroids, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mm, mm0, sizeof mm0, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, (size_t)N * 2 * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) {
+        const int gx = (int)((npx + 255) / 256);
+        hipLaunchKernelGGL(k_radlong_project, dim3(gx < 256 ? gx : 256, N), dim3(256), 0, h->stream, dflow, dcent, H, W, h->an_rad, h->an_lon, mm, cnt);
+        e = hipMemcpyAsync(mmh, mm, sizeof mmh, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ch.data(), cnt, ch.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && rad_out) e = hipMemcpyAsync(rad_out, h->an_rad, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && long_out) e = hipMemcpyAsync(long_out, h->an_lon, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(dflow); (void)hipFree(dcent); (void)hipFree(mm); (void)hipFree(cnt);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "tf_radlong_project: %s", hipGetErrorString(e));
+    for (int j = 0; j < 4; ++j) minmax[j] = f64_unkey(mmh[j]);
+    for (size_t i = 0; i < ch.size(); ++i) nonzero[i] = (long long)ch[i];
+    h->anN = N; h->anH = H; h->anW = W;
+    return TF_OK;
+}
+
+TF_API int tf_radlong_hist(tf_handle* h, int which, const double* edges, int nbins, long long* freq_out)
+{
+    if (!h || !edges || !freq_out || nbins < 1 || which < 0 || which > 1) return TF_ERR_INVALID_ARG;
+    if (h->anN < 1) return fail(h, TF_ERR_INVALID_ARG, "tf_radlong_hist needs a preceding tf_radlong_project");
+    HIPC(h, hipSetDevice(h->dev));
+    const size_t npx = (size_t)h->anH * h->anW;
+    double* de = nullptr; unsigned long long* df = nullptr;
+    HIPC(h, hipMalloc(&de, (size_t)(nbins + 1) * sizeof(double)));
+    hipError_t e = hipMalloc(&df, (size_t)h->anN * nbins * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(de, edges, (size_t)(nbins + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(df, 0, (size_t)h->anN * nbins * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) {
+        const int gx = (int)((npx + 255) / 256);
+        hipLaunchKernelGGL(k_radlong_hist, dim3(gx < 256 ? gx : 256, h->anN), dim3(256), 0, h->stream, which ? h->an_lon : h->an_rad, npx, de, nbins, df);
+        e = hipMemcpyAsync(freq_out, df, (size_t)h->anN * nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(de); (void)hipFree(df);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "tf_radlong_hist: %s", hipGetErrorString(e));
+    return TF_OK;
+}
+
+TF_API int tf_radlong_select(tf_handle* h, int which, const long long* ranks, double* values_out)
+{
+    if (!h || !ranks || !values_out || which < 0 || which > 1) return TF_ERR_INVALID_ARG;
+    if (h->anN < 1) return fail(h, TF_ERR_INVALID_ARG, "tf_radlong_select needs a preceding tf_radlong_project");
+    HIPC(h, hipSetDevice(h->dev));
+    const int N = h->anN, NS = N * RL_NSLOT;
+    const size_t npx = (size_t)h->anH * h->anW;
+    u64* pf = nullptr; long long* rk = nullptr; int* ac = nullptr; unsigned* hist = nullptr;
+    std::vector<int> act((size_t)NS);
+    for (int i = 0; i < NS; ++i) act[i] = ranks[i] >= 0;
+    HIPC(h, hipMalloc(&pf, (size_t)NS * sizeof(u64)));
+    hipError_t e = hipMalloc(&rk, (size_t)NS * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&ac, (size_t)NS * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&hist, (size_t)NS * 65536 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(pf, 0, (size_t)NS * sizeof(u64), h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rk, ranks, (size_t)NS * sizeof(long long), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ac, act.data(), (size_t)NS * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    const double* v = which ? h->an_lon : h->an_rad;
+    const int gx = (int)((npx + 255) / 256);
+    for (int shift = 48; shift >= 0 && e == hipSuccess; shift -= 16) {
+        e = hipMemsetAsync(hist, 0, (size_t)NS * 65536 * sizeof(unsigned), h->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_radlong_sel_hist, dim3(gx < 256 ? gx : 256, N), dim3(256), 0, h->stream, v, npx, shift, pf, ac, hist);
+        hipLaunchKernelGGL(k_radlong_sel_scan, dim3(NS), dim3(256), 0, h->stream, hist, shift, pf, rk, ac);
+    }
+    std::vector<u64> keys((size_t)NS);
+    if (e == hipSuccess) e = hipMemcpyAsync(keys.data(), pf, (size_t)NS * sizeof(u64), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(pf); (void)hipFree(rk); (void)hipFree(ac); (void)hipFree(hist);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "tf_radlong_select: %s", hipGetErrorString(e));
+    for (int i = 0; i < NS; ++i) values_out[i] = act[i] ? f64_unkey(keys[i]) : 0.0;
+    return TF_OK;
 }
 
 TF_API int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written)
