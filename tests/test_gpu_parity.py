@@ -229,3 +229,68 @@ def test_study_from_rgb_on_device_equals_host_conditioned_path(engine, oracle):
     fr = condition_frames(nparr)
     assert out.shape == (5, 64, 80, 2) and np.array_equal(out[3], out[4])
     assert np.array_equal(out[0], oracle.tvl1_calc(fr[0], fr[1]) * (0.05 * 30.0))
+
+
+def test_config5_process_video_to_hdf5_on_gpu(tmp_path, oracle):
+    """BASELINE config 5 (as far as the offline image allows): a synthetic 256x256 study injected at the nparr level ->
+    masks (Otsu path; SAM's result would be passed as mask_dict=) -> device conditioning + DualTVL1 on the GPU -> duplicated
+    last flow, unit scale -> HDF5 with the reference's keys / dtypes / shapes / attrs.  h5py only exists in the image's second
+    interpreter, so the study driver runs there (the engine needs ctypes + numpy only)."""
+    import json
+    import os
+    import subprocess
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        pytest.skip("no interpreter with h5py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "study.h5")
+    script = f"""
+import sys, json, numpy as np
+sys.path.insert(0, {root!r})
+import h5py
+from scipy import ndimage
+from tee_optical_flow_amd.pipeline import process_video
+rng = np.random.default_rng(1000)
+N, H, W = 6, 256, 256
+yy, xx = np.mgrid[0:H, 0:W]
+base = ndimage.gaussian_filter(rng.standard_normal((H + 40, W + 40)), 2.5)
+base = (base - base.min()) / (base.max() - base.min()) * 255
+blob = np.exp(-(((xx - 128) / 70.0) ** 2 + ((yy - 128) / 60.0) ** 2))
+frames = np.stack([np.clip(base[20 + i:20 + i + H, 20 + 2 * i:20 + 2 * i + W] * (0.25 + 0.75 * blob), 0, 255) for i in range(N)]).astype(np.uint8)
+nparr = np.repeat(frames[..., None], 3, axis=3)
+md = {{"pixel_spacing": 0.04, "frame_rate": 50.0, "R_wave_data_present": False, "R_times": None}}
+flow = process_video(None, {out!r}, None, verbose=False, mode="otsu", no_saliency=True, nparr=nparr, metadata=md, patient_id="SYNTH-5", heart_rate=61)
+np.save({str(tmp_path / 'flow.npy')!r}, flow)
+np.save({str(tmp_path / 'nparr.npy')!r}, nparr)
+d = {{}}
+with h5py.File({out!r}, "r") as f:
+    for k in f.keys():
+        ds = f[k]
+        d[k] = {{"dtype": str(ds.dtype), "shape": list(ds.shape), "compression": ds.compression, "compression_opts": ds.compression_opts,
+                "attrs": {{n: [type(v).__name__, str(np.asarray(v).dtype)] for n, v in ds.attrs.items()}}}}
+    ok = bool(np.array_equal(f["flow"][...], flow.astype(np.float16)))
+print(json.dumps({{"layout": d, "payload_ok": ok}}))
+"""
+    env = {**os.environ, "PYTHONDONTWRITEBYTECODE": "1"}
+    sys_stdcpp = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"       # conda ships an older libstdc++ than libamdhip64 needs
+    if os.path.exists(sys_stdcpp):
+        env["LD_PRELOAD"] = sys_stdcpp
+    r = subprocess.run([py, "-c", script], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["payload_ok"]
+    ref = json.load(open(os.path.join(root, "tests", "golden", "reference_host_side.json")))["hdf5_layout"]["no_waveforms"]
+    lay = got["layout"]
+    assert sorted(lay) == sorted(k for k in ref if k != "RWaveTime")          # echo, flow, otsu (no R-wave data in this study)
+    for k in lay:
+        assert lay[k]["dtype"] == ref[k]["dtype"] and lay[k]["compression"] == "gzip" and lay[k]["compression_opts"] == 9
+        assert sorted(lay[k]["attrs"]) == sorted(ref[k]["attrs"])                       # same attribute names ...
+        for a_, v_ in lay[k]["attrs"].items():
+            assert v_ == ref[k]["attrs"][a_][:2], (k, a_)                               # ... with the same Python / numpy types
+    assert lay["flow"]["shape"] == [6, 256, 256, 2] and lay["echo"]["shape"] == [6, 256, 256] and lay["otsu"]["shape"] == [6, 256, 256, 2]
+    # the flow itself: first pair against the oracle on the conditioned frames, times pixel_spacing * frame_rate
+    from tee_optical_flow_amd.frames import condition_frames
+    flow = np.load(str(tmp_path / "flow.npy"))
+    fr = condition_frames(np.load(str(tmp_path / "nparr.npy")))
+    assert np.array_equal(flow[0], oracle.tvl1_calc(fr[0], fr[1]) * (0.04 * 50.0))
+    assert np.array_equal(flow[-1], flow[-2])
