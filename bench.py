@@ -195,7 +195,7 @@ def main():
                          "measured_on": f"{a.steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
         else:
             whole = acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None
-            ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<2> (red-black SOR, 2 sweeps per launch; ~86% of device time)",
+            ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<3> (red-black SOR, 3 sweeps per launch on LDS tiles; dominant)",
                     "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (whole / HBM_PEAK_GBS) if whole else None, "traffic": None,
                     "note": "whole-solve figure: algorithmic bytes of all DeepFlow kernels (one colour per launch SOR accounting, "
                             "df_account_bytes) / device time; per-launch event instrumentation exists for tvl1_iter only"}

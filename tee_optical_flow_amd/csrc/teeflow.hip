@@ -88,7 +88,7 @@ struct tf_handle {
                                  // while one lane runs the thin tail of a stage, the other fills the GPU (+6 % measured; 4 lanes lose)
     tf_handle* twin = nullptr; bool is_twin = false;
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
-    int sor_fuse = 2;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 2 measured best
+    int sor_fuse = 3;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 3 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
     int min_rows_work = 4096;    // rows*pairs below which the tile kernel is used (tiny launches / single-pair latency)

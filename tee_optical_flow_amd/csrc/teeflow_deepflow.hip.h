@@ -207,44 +207,63 @@ __global__ __launch_bounds__(256) void k_df_sor(DfBufs d, Geom g, int color, flo
 // neighbouring tiles still read this tile's (du, dv) as their halo.  HBM traffic per sweep drops ~3x at S = 2.
 // Each thread owns NS "slots" (row, column pair); a slot holds one red and one black pixel, so in every half-sweep all
 // lanes have work (no idle colour), and the slot's geometry flags are computed once.
+// LDS holds even-x and odd-x pixels in separate arrays (same-colour pixels of a row are then contiguous: no 2-way bank
+// conflicts of a stride-2 access), and a slot's two pixels are fetched / written back with one 8-byte access per plane.
 template <int S>
 __global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float omega)
 {
     constexpr int HL = 2 * S, TW = 64, TH = 32, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sdu = smem;
-    float* sdv = sdu + RW * RH;
-    float* swg = sdv + RW * RH;
-    const int b = blockIdx.z, x0 = blockIdx.x * TW - HL, y0 = blockIdx.y * TH - HL;
+    // LDS planes [x parity][ry * HW + rx / 2]: du at (0 + parity) * NSLOT, dv at (2 + parity) * NSLOT, weights at (4 + parity) * NSLOT
+    // (addressed by offset: pointer arrays initialised from the LDS base trip a static-initializer limitation of the compiler)
+    constexpr int ODU = 0, ODV = 2 * NSLOT, OWG = 4 * NSLOT;
+    const int b = blockIdx.z, x0 = blockIdx.x * TW - HL, y0 = blockIdx.y * TH - HL;   // x0 is even
     const int W = g.w, H = g.h, pitch = g.pitch;
     const size_t po = (size_t)b * g.splane;
-    // per slot and colour c (0 = (x+y) even): LDS index, flags, coefficients
-    int pidx[2][NS];
-    unsigned flg[2][NS];        // bit0 update allowed, bit1 has left, bit2 has right, bit3 has up, bit4 has down, bit5 write back
+    // per slot and colour c (0 = (x+y) even): flags and coefficients of the slot's pixel of that colour
+    unsigned flg[2][NS];   // bit0 update allowed, bit1 has left, bit2 has right, bit3 has up, bit4 has down, bit5 write back, bit6 x parity
     float a11[2][NS], a12[2][NS], a22[2][NS], b1[2][NS], b2[2][NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int q = threadIdx.x + k * 256;
         const int ry = q / HW, qx = q - ry * HW;
+        const int gy = y0 + ry, gxe = x0 + 2 * qx;
+        float2 vdu = make_float2(0, 0), vdv = vdu, vw = vdu, v11 = make_float2(1, 1), v12 = vdu, v22 = v11, vb1 = vdu, vb2 = vdu;
+        const bool rowok = q < NSLOT && gy >= 0 && gy < H;
+        if (rowok && gxe >= 0 && gxe + 1 < W) {
+            const size_t i = po + (size_t)gy * pitch + gxe;
+            vdu = *reinterpret_cast<const float2*>(d.du + i); vdv = *reinterpret_cast<const float2*>(d.dv + i);
+            vw = *reinterpret_cast<const float2*>(d.wg + i);
+            v11 = *reinterpret_cast<const float2*>(d.A11 + i); v12 = *reinterpret_cast<const float2*>(d.A12 + i);
+            v22 = *reinterpret_cast<const float2*>(d.A22 + i);
+            vb1 = *reinterpret_cast<const float2*>(d.b1 + i); vb2 = *reinterpret_cast<const float2*>(d.b2 + i);
+        } else if (rowok) {
+            if (gxe >= 0 && gxe < W) {
+                const size_t i = po + (size_t)gy * pitch + gxe;
+                vdu.x = d.du[i]; vdv.x = d.dv[i]; vw.x = d.wg[i]; v11.x = d.A11[i]; v12.x = d.A12[i]; v22.x = d.A22[i]; vb1.x = d.b1[i]; vb2.x = d.b2[i];
+            }
+            if (gxe + 1 >= 0 && gxe + 1 < W) {
+                const size_t i = po + (size_t)gy * pitch + gxe + 1;
+                vdu.y = d.du[i]; vdv.y = d.dv[i]; vw.y = d.wg[i]; v11.y = d.A11[i]; v12.y = d.A12[i]; v22.y = d.A22[i]; vb1.y = d.b1[i]; vb2.y = d.b2[i];
+            }
+        }
+        if (q < NSLOT) {
+            smem[ODU + q] = vdu.x; smem[ODU + NSLOT + q] = vdu.y; smem[ODV + q] = vdv.x; smem[ODV + NSLOT + q] = vdv.y;
+            smem[OWG + q] = vw.x; smem[OWG + NSLOT + q] = vw.y;
+        }
+        const int ce = (x0 + y0 + ry) & 1;                        // colour of the slot's even-x pixel
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int rx = 2 * qx + ((c + x0 + y0 + ry) & 1);
-            const int gx = x0 + rx, gy = y0 + ry;
-            const int p = ry * RW + rx;
-            const bool inimg = q < NSLOT && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            float du = 0.f, dv = 0.f, w = 0.f;
-            a11[c][k] = a22[c][k] = 1.f; a12[c][k] = b1[c][k] = b2[c][k] = 0.f;
-            if (inimg) {
-                const size_t i = po + (size_t)gy * pitch + gx;
-                du = d.du[i]; dv = d.dv[i]; w = d.wg[i];
-                a11[c][k] = d.A11[i]; a12[c][k] = d.A12[i]; a22[c][k] = d.A22[i]; b1[c][k] = d.b1[i]; b2[c][k] = d.b2[i];
-            }
-            if (q < NSLOT) { sdu[p] = du; sdv[p] = dv; swg[p] = w; }
+            const bool odd = c != ce;                             // the pixel of colour c is the odd-x one
+            a11[c][k] = odd ? v11.y : v11.x; a12[c][k] = odd ? v12.y : v12.x; a22[c][k] = odd ? v22.y : v22.x;
+            b1[c][k] = odd ? vb1.y : vb1.x; b2[c][k] = odd ? vb2.y : vb2.x;
+            const int rx = 2 * qx + (odd ? 1 : 0), gx = x0 + rx;
+            const bool inimg = rowok && gx >= 0 && gx < W;
             // a pixel can be updated when each neighbour is either outside the image (no edge) or inside the staged region
             const bool ok = inimg && (gx == 0 || rx > 0) && (gx == W - 1 || rx < RW - 1) && (gy == 0 || ry > 0) && (gy == H - 1 || ry < RH - 1);
             const bool wb = inimg && rx >= HL && rx < HL + TW && ry >= HL && ry < HL + TH;
-            pidx[c][k] = p;
-            flg[c][k] = (ok ? 1u : 0u) | (gx > 0 ? 2u : 0u) | (gx < W - 1 ? 4u : 0u) | (gy > 0 ? 8u : 0u) | (gy < H - 1 ? 16u : 0u) | (wb ? 32u : 0u);
+            flg[c][k] = (ok ? 1u : 0u) | (gx > 0 ? 2u : 0u) | (gx < W - 1 ? 4u : 0u) | (gy > 0 ? 8u : 0u) | (gy < H - 1 ? 16u : 0u) |
+                        (wb ? 32u : 0u) | (odd ? 64u : 0u);
         }
     }
     __syncthreads();
@@ -256,35 +275,48 @@ __global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float om
             for (int k = 0; k < NS; ++k) {
                 const unsigned f = flg[c][k];
                 if (f & 1u) {
-                    const int p = pidx[c][k];
-                    const float ws = swg[p];
-                    const float wl = (f & 2u) ? swg[p - 1] : 0.f, wu_ = (f & 8u) ? swg[p - RW] : 0.f;
+                    const int q = threadIdx.x + k * 256;
+                    const int par = (f >> 6) & 1;
+                    // own-parity arrays hold the pixel and its vertical neighbours; the other parity holds left / right
+                    float* duA = smem + ODU + par * NSLOT; float* dvA = smem + ODV + par * NSLOT;
+                    const float* wA = smem + OWG + par * NSLOT;
+                    const float* duB = smem + ODU + (par ^ 1) * NSLOT; const float* dvB = smem + ODV + (par ^ 1) * NSLOT;
+                    const float* wB = smem + OWG + (par ^ 1) * NSLOT;
+                    const int li = par ? q : q - 1, ri = par ? q + 1 : q;
+                    const float ws = wA[q];
+                    const float wl = (f & 2u) ? wB[li] : 0.f, wu_ = (f & 8u) ? wA[q - HW] : 0.f;
                     const float wr = (f & 4u) ? ws : 0.f, wd = (f & 16u) ? ws : 0.f;
-                    const float dul = (f & 2u) ? sdu[p - 1] : 0.f, dur = (f & 4u) ? sdu[p + 1] : 0.f;
-                    const float duu = (f & 8u) ? sdu[p - RW] : 0.f, dud = (f & 16u) ? sdu[p + RW] : 0.f;
-                    const float dvl = (f & 2u) ? sdv[p - 1] : 0.f, dvr = (f & 4u) ? sdv[p + 1] : 0.f;
-                    const float dvu = (f & 8u) ? sdv[p - RW] : 0.f, dvd = (f & 16u) ? sdv[p + RW] : 0.f;
+                    const float dul = (f & 2u) ? duB[li] : 0.f, dur = (f & 4u) ? duB[ri] : 0.f;
+                    const float duu = (f & 8u) ? duA[q - HW] : 0.f, dud = (f & 16u) ? duA[q + HW] : 0.f;
+                    const float dvl = (f & 2u) ? dvB[li] : 0.f, dvr = (f & 4u) ? dvB[ri] : 0.f;
+                    const float dvu = (f & 8u) ? dvA[q - HW] : 0.f, dvd = (f & 16u) ? dvA[q + HW] : 0.f;
                     const float sigmaU = wl * dul + wr * dur + wu_ * duu + wd * dud;
                     const float sigmaV = wl * dvl + wr * dvr + wu_ * dvu + wd * dvd;
-                    float du = sdu[p], dv = sdv[p];
+                    float du = duA[q], dv = dvA[q];
                     du += omega * ((sigmaU + b1[c][k] - dv * a12[c][k]) / a11[c][k] - du);
                     dv += omega * ((sigmaV + b2[c][k] - du * a12[c][k]) / a22[c][k] - dv);
-                    sdu[p] = du; sdv[p] = dv;
+                    duA[q] = du; dvA[q] = dv;
                 }
             }
             __syncthreads();
         }
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-            if (flg[c][k] & 32u) {
-                const int p = pidx[c][k];
-                const int ry = p / RW, rx = p - ry * RW;
-                const size_t i = po + (size_t)(y0 + ry) * pitch + (x0 + rx);
-                d.du2[i] = sdu[p]; d.dv2[i] = sdv[p];       // other tiles still read (du, dv) of this tile as their halo
+    for (int k = 0; k < NS; ++k) {
+        const unsigned f0 = flg[0][k], f1 = flg[1][k];
+        if ((f0 | f1) & 32u) {
+            const int q = threadIdx.x + k * 256;
+            const int ry = q / HW, qx = q - ry * HW;
+            const size_t i = po + (size_t)(y0 + ry) * pitch + (x0 + 2 * qx);   // other tiles still read (du, dv) of this tile as halo
+            if ((f0 & f1) & 32u) {
+                *reinterpret_cast<float2*>(d.du2 + i) = make_float2(smem[ODU + q], smem[ODU + NSLOT + q]);
+                *reinterpret_cast<float2*>(d.dv2 + i) = make_float2(smem[ODV + q], smem[ODV + NSLOT + q]);
+            } else {
+                const int odd = ((f0 & 32u) ? f0 : f1) >> 6 & 1;
+                d.du2[i + odd] = smem[ODU + odd * NSLOT + q]; d.dv2[i + odd] = smem[ODV + odd * NSLOT + q];
             }
+        }
+    }
 }
 
 // W + dW of this level -> flow of the next finer level (resize INTER_LINEAR to its size, times 1/downscaleFactor)
