@@ -158,7 +158,7 @@ def main():
         dt = float(t.item())
     # Roofline leg: the SAME K steps again with every tvl1_iter launch bracketed by a HIP event pair on the engine's
     # stream.  Kept out of the timed region above because ~1200 event records per step cost ~8% of a step.
-    if not a.no_profile and a.algo == "TVL1":
+    if not a.no_profile:
         eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include the other lane's kernels
         eng.set_profile(1)
         for k in range(a.steps):
@@ -194,11 +194,13 @@ def main():
                                  "and the kernel is bound by fp32/fp64 VALU issue (see DESIGN.md section 4)",
                          "measured_on": f"{a.steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
         else:
-            whole = acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None
             ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<3> (red-black SOR, 3 sweeps per launch on LDS tiles; dominant)",
-                    "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (whole / HBM_PEAK_GBS) if whole else None, "traffic": None,
-                    "note": "whole-solve figure: algorithmic bytes of all DeepFlow kernels (one colour per launch SOR accounting, "
-                            "df_account_bytes) / device time; per-launch event instrumentation exists for tvl1_iter only"}
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms, "launches": acc["iter_launches"],
+                    "bytes_per_px_sweep": 80,
+                    "note": "achieved = executed pixel-sweeps x 80 B (the one-colour-per-launch form's traffic: 8 plane reads + 2 writes per "
+                            "colour pass) / summed launch time, one HIP event pair per launch, single lane; the fused kernel moves about a "
+                            "third of that through HBM"}
         out = {
             "metric": "frame-pairs/sec @512x512 " + ("DualTVL1" if a.algo == "TVL1" else "DeepFlow"), "value": pairs / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -228,10 +230,23 @@ def main():
         torch.cuda.synchronize(dev)
         out["latency_ms_single_pair"] = (time.perf_counter() - tl) / 10 * 1e3
         lat_eng.close()
+        # the same step through the host-pointer entry point (PCIe in and out included) -- reported beside, never as `value`
+        fh = np.empty((B, H, W, 2), np.float32)
+        eng.calc_pairs(I0s, I1s)
+        tp = time.perf_counter()
+        eng.calc_pairs(I0s, I1s)
+        out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
+        del fh
         if world == 1 and not a.no_cpu_baseline:
             n = min(a.cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n, a.algo)
             out["cpu_baseline"] = cb
+            from oracle import oracle as O
+            O.set_num_threads(1)
+            t1 = time.perf_counter()
+            (O.tvl1_calc if a.algo == "TVL1" else O.deepflow_calc)(I0s[0], I1s[0])
+            out["cpu_baseline_1_thread_pairs_per_s"] = 1.0 / (time.perf_counter() - t1)
+            O.set_num_threads(O.effective_cpus())
             last = a.warmup + a.steps - 1 + (0 if a.no_profile else a.steps)
             got = flows[last & 1][:n].cpu().numpy()
             diff = max(float(np.abs(got[i] - ref[i]).max()) for i in range(n))

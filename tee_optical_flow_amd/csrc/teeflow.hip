@@ -70,6 +70,7 @@ struct tf_handle {
     std::vector<int> last_iters; int last_pairs = 0, last_nlev = 0, last_warps = 0;
     // per-call accumulators
     unsigned long long iter_launches = 0;
+    double df_sor_bytes = 0;     // DeepFlow: algorithmic bytes of the SOR launches of the current call (80 B per pixel-sweep)
     // ---- DeepFlow (algo == TF_ALGO_DEEPFLOW) ----
     tf_deepflow_params DP = {};
     int dnlev = 0, dH = 0, dW = 0, dcap = 0;
@@ -591,6 +592,16 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
                 --left;
                 continue;
             }
+            ProfEv* pe = nullptr;
+            if (h->profile) {
+                if (h->prof_used == h->prof_pool.size()) {
+                    ProfEv ne;
+                    if (hipEventCreate(&ne.a) == hipSuccess && hipEventCreate(&ne.b) == hipSuccess) h->prof_pool.push_back(ne);
+                }
+                if (h->prof_used < h->prof_pool.size()) { pe = &h->prof_pool[h->prof_used++]; (void)hipEventRecord(pe->a, s); }
+            }
+            ++h->iter_launches;
+            h->df_sor_bytes += (double)n * g.w * g.h * B * 80.0;
             switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
                 case 1: launch_sor_fused<1>(d, g, B, c.omega, s); break;
                 case 2: launch_sor_fused<2>(d, g, B, c.omega, s); break;
@@ -598,6 +609,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
                 case 4: launch_sor_fused<4>(d, g, B, c.omega, s); break;
                 default: launch_sor_fused<5>(d, g, B, c.omega, s); break;
             }
+            if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
             left -= n;
         }
@@ -670,7 +682,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     const size_t fpx = (size_t)H * W;
     h->last_iters.assign(deep ? 0 : (size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
     h->last_pairs = n_pairs; h->last_nlev = deep ? h->dnlev : h->nlev; h->last_warps = deep ? 0 : h->P.warps;
-    h->iter_launches = 0; h->prof_used = 0;
+    h->iter_launches = 0; h->prof_used = 0; h->df_sor_bytes = 0;
     float ms_h2d = 0, ms_dev = 0, ms_d2h = 0;
     if (!device) {
         rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, (size_t)h->cap * fpx * 2 * sizeof(float));
@@ -718,7 +730,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         st->n_pairs = n_pairs; st->nscales_used = deep ? h->dnlev : h->nlev; st->warps = deep ? 0 : h->P.warps;
         st->ms_h2d = ms_h2d; st->ms_device = ms_dev; st->ms_d2h = ms_d2h;
         st->iter_launches = h->iter_launches;
-        if (deep) st->total_bytes = df_account_bytes(h) * n_pairs;
+        if (deep) { st->total_bytes = df_account_bytes(h) * n_pairs; st->iter_bytes = h->df_sor_bytes; }
         for (int b = 0; !deep && b < n_pairs; ++b)
             account_bytes(h, h->last_iters.data() + (size_t)b * h->nlev * h->P.warps * 2, &st->iter_bytes, &st->total_bytes,
                           &st->inner_iters_total, &st->outer_iters_total);
