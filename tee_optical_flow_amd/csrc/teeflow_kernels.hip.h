@@ -508,6 +508,153 @@ __device__ __forceinline__ void tv_p_quad(float taut, const float* u1x, const fl
     }
 }
 
+// ---- packed forms used by k_iter2_rows ------------------------------------------------------------------------
+// The iteration kernel is VALU-bound (non-packed fp32 issues one wave64 instruction per 4 cycles), so the pointwise part
+// of the quad helpers is written on float2 values spanning two NEIGHBOURING PIXELS: they sit in adjacent registers of the
+// dwordx4 loads, so v_pk_mul/add/fma_f32 apply without shuffles.  Same operations in the same order as the scalar forms
+// above, hence the same bits.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// IEEE a/b as hipcc lowers it (v_rcp_f32, one Newton step on the reciprocal, two on the quotient, v_div_fixup_f32), with
+// two changes that keep the bits: (1) the refined reciprocal is shared by the quotients that have the same denominator;
+// (2) instead of v_div_scale's case analysis, numerator AND denominator are always scaled by 2^64 -- what v_div_scale does
+// for a tiny numerator.  The quotient is unchanged, a power of two commutes with every rounding in the chain, and the
+// remainders fma(-b, q, a) cannot underflow.  A quotient in the denormal range is rounded once, by the last fma, like
+// v_div_fmas does.  Valid for 2^-24 < |b| < 2^60 and |a| < 2^60 -- here b is 1 + taut*|grad u| >= 1 or |grad I|^2 in
+// (2^-23, 2^24) and |a| stays far below 2^60.  `rcp2s` returns 1/(b*2^64).
+__device__ __forceinline__ f2 rcp2s(f2 bs)
+{
+    const f2 r = mk2(__builtin_amdgcn_rcpf(bs.x), __builtin_amdgcn_rcpf(bs.y));
+    const f2 e = fma2(-bs, r, mk2(1.0f, 1.0f));
+    return fma2(e, r, r);
+}
+__device__ __forceinline__ f2 div2s(f2 a, f2 b, f2 bs, f2 rs)
+{
+    const f2 as = a * 0x1p64f;
+    f2 q = as * rs;
+    f2 e = fma2(-bs, q, as);
+    q = fma2(e, rs, q);
+    e = fma2(-bs, q, as);
+    q = fma2(e, rs, q);
+    return mk2(__builtin_amdgcn_div_fixupf(q.x, b.x, a.x), __builtin_amdgcn_div_fixupf(q.y, b.y, a.y));
+}
+
+// hypot_exact without the x == inf test (a, b are floats: x <= 2^257) and with the x == 0 case folded into a clamp
+// (the smallest non-zero x is 2^-298; sqrt(2^-400) converts to 0.0f like sqrt(0))
+__device__ __forceinline__ float hypot_exact2(float a, float b)
+{
+    const double ad = (double)a, bd = (double)b;
+    const double x = __builtin_fmax(__builtin_fma(ad, ad, bd * bd), 0x1p-400);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (float)g;
+}
+
+// estimateV + divergence + estimateU for two neighbouring pixels; `first` = this is the pair that holds pixel x == 0 of
+// the row when x0 is set (only that pixel uses the first-column form of the divergence)
+__device__ __forceinline__ void tv_u_pair(float l_t, float theta, f2 u1k, f2 u2k, f2 wx, f2 wy, f2 rc, f2 p11, f2 p12, f2 p21,
+                                          f2 p22, f2 p12u, f2 p22u, float l11, float l21, bool ytop, bool x0, f2& u1n, f2& u2n)
+{
+    const f2 Ix2 = wx * wx, Iy2 = wy * wy;
+    const f2 grad = Ix2 + Iy2;
+    const f2 rho = rc + (wx * u1k + wy * u2k);
+    const f2 lg = l_t * grad;
+    const f2 grads = grad * 0x1p64f;
+    const f2 fi = div2s(-rho, grad, grads, rcp2s(grads));
+    const bool c1x = rho.x < -lg.x, c2x = rho.x > lg.x, c3x = grad.x > FLT_EPSILON;
+    const bool c1y = rho.y < -lg.y, c2y = rho.y > lg.y, c3y = grad.y > FLT_EPSILON;
+    const f2 k = mk2(c1x ? l_t : (c2x ? -l_t : fi.x), c1y ? l_t : (c2y ? -l_t : fi.y));
+    const f2 kd1 = k * wx, kd2 = k * wy;
+    const bool anyx = c1x || c2x || c3x, anyy = c1y || c2y || c3y;
+    const f2 d1 = mk2(anyx ? kd1.x : 0.f, anyy ? kd1.y : 0.f), d2 = mk2(anyx ? kd2.x : 0.f, anyy ? kd2.y : 0.f);
+    const f2 v1 = u1k + d1, v2 = u2k + d2;
+    const f2 dx1 = mk2(p11.x - l11, p11.y - p11.x), dx2 = mk2(p21.x - l21, p21.y - p21.x);
+    f2 div1, div2_;
+    if (!ytop) {
+        div1 = dx1 + (p12 - p12u); div2_ = dx2 + (p22 - p22u);
+        const float b1 = (p11.x + p12.x) - p12u.x, b2 = (p21.x + p22.x) - p22u.x;
+        div1.x = x0 ? b1 : div1.x; div2_.x = x0 ? b2 : div2_.x;
+    } else {
+        div1 = dx1 + p12; div2_ = dx2 + p22;
+        const float b1 = p11.x + p12.x, b2 = p21.x + p22.x;
+        div1.x = x0 ? b1 : div1.x; div2_.x = x0 ? b2 : div2_.x;
+    }
+    u1n = v1 + theta * div1;
+    u2n = v2 + theta * div2_;
+}
+
+__device__ __forceinline__ void tv_u_quad_pk(float l_t, float theta, const QuadU& q, bool ytop, bool x0, float* u1n, float* u2n)
+{
+    f2 a1, a2, b1, b2;
+    tv_u_pair(l_t, theta, mk2(q.u1k[0], q.u1k[1]), mk2(q.u2k[0], q.u2k[1]), mk2(q.wx[0], q.wx[1]), mk2(q.wy[0], q.wy[1]),
+              mk2(q.r[0], q.r[1]), mk2(q.p11[0], q.p11[1]), mk2(q.p12[0], q.p12[1]), mk2(q.p21[0], q.p21[1]),
+              mk2(q.p22[0], q.p22[1]), mk2(q.p12u[0], q.p12u[1]), mk2(q.p22u[0], q.p22u[1]), q.l11, q.l21, ytop, x0, a1, a2);
+    tv_u_pair(l_t, theta, mk2(q.u1k[2], q.u1k[3]), mk2(q.u2k[2], q.u2k[3]), mk2(q.wx[2], q.wx[3]), mk2(q.wy[2], q.wy[3]),
+              mk2(q.r[2], q.r[3]), mk2(q.p11[2], q.p11[3]), mk2(q.p12[2], q.p12[3]), mk2(q.p21[2], q.p21[3]),
+              mk2(q.p22[2], q.p22[3]), mk2(q.p12u[2], q.p12u[3]), mk2(q.p22u[2], q.p22u[3]), q.p11[1], q.p21[1], ytop, false, b1, b2);
+    u1n[0] = a1.x; u1n[1] = a1.y; u1n[2] = b1.x; u1n[3] = b1.y;
+    u2n[0] = a2.x; u2n[1] = a2.y; u2n[2] = b2.x; u2n[3] = b2.y;
+}
+
+// convergence terms of a quad, added to a double accumulator: every term is an integer below 2^43, so the sum is exact
+// while it stays below 2^53 (the caller folds the accumulator into a u64 every 256 steps)
+// `keep[i]` is all-ones for a pixel that counts and 0 for one that does not (halo rows, columns >= W).  Masks, not
+// selects: a v_cndmask whose VCC was produced by the scalar unit (row predicate AND column predicate) costs ~23 cycles on
+// gfx950 against 2.5 for a v_and.
+__device__ __forceinline__ unsigned opaque_u(unsigned m) { asm volatile("" : "+v"(m)); return m; }
+__device__ __forceinline__ float mask_f(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
+__device__ __forceinline__ double tv_err_quad_pk(const float* u1n, const float* u1k, const float* u2n, const float* u2k,
+                                                 const unsigned* keep)
+{
+    const f2 e1a = mk2(u1n[0], u1n[1]) - mk2(u1k[0], u1k[1]), e2a = mk2(u2n[0], u2n[1]) - mk2(u2k[0], u2k[1]);
+    const f2 e1b = mk2(u1n[2], u1n[3]) - mk2(u1k[2], u1k[3]), e2b = mk2(u2n[2], u2n[3]) - mk2(u2k[2], u2k[3]);
+    const f2 ta = e1a * e1a + e2a * e2a, tb = e1b * e1b + e2b * e2b;
+    const float t[4] = {ta.x, ta.y, tb.x, tb.y};
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = __builtin_rintf(fminf(t[i], ERR_CAP_F) * ERR_SCALE_F);
+        acc += (double)mask_f(v, keep[i]);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void tv_p_pair(float taut, f2 u1x, f2 u1y, f2 u2x, f2 u2y, f2 p11, f2 p12, f2 p21, f2 p22,
+                                          f2& o11, f2& o12, f2& o21, f2& o22)
+{
+    const f2 g1 = mk2(hypot_exact2(u1x.x, u1y.x), hypot_exact2(u1x.y, u1y.y));
+    const f2 g2 = mk2(hypot_exact2(u2x.x, u2y.x), hypot_exact2(u2x.y, u2y.y));
+    const f2 ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
+    const f2 ns1 = ng1 * 0x1p64f, ns2 = ng2 * 0x1p64f;
+    const f2 r1 = rcp2s(ns1), r2 = rcp2s(ns2);
+    o11 = div2s(p11 + taut * u1x, ng1, ns1, r1); o12 = div2s(p12 + taut * u1y, ng1, ns1, r1);
+    o21 = div2s(p21 + taut * u2x, ng2, ns2, r2); o22 = div2s(p22 + taut * u2y, ng2, ns2, r2);
+}
+
+__device__ __forceinline__ void tv_p_quad_pk(float taut, const float* u1x, const float* u1y, const float* u2x, const float* u2y,
+                                             const float* p11, const float* p12, const float* p21, const float* p22,
+                                             float* o11, float* o12, float* o21, float* o22)
+{
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+        f2 a, b, c, d;
+        tv_p_pair(taut, mk2(u1x[h], u1x[h + 1]), mk2(u1y[h], u1y[h + 1]), mk2(u2x[h], u2x[h + 1]), mk2(u2y[h], u2y[h + 1]),
+                  mk2(p11[h], p11[h + 1]), mk2(p12[h], p12[h + 1]), mk2(p21[h], p21[h + 1]), mk2(p22[h], p22[h + 1]), a, b, c, d);
+        o11[h] = a.x; o11[h + 1] = a.y; o12[h] = b.x; o12[h + 1] = b.y;
+        o21[h] = c.x; o21[h + 1] = c.y; o22[h] = d.x; o22[h + 1] = d.y;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_iter(IterArgs a)
 {
     __shared__ __attribute__((aligned(16))) float su1[IT_TH][IT_TW + 4];
@@ -845,7 +992,8 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     // row predicates (absolute row index)
     const int yu1_lo = y0 - 1, yu1_hi = y0 + R + 1, yp1_hi = y0 + R, yout_hi = y0 + R - 1;
 
-    // pipeline registers
+    // pipeline registers.  Written only under the predicate (s1_valid / s2_valid) they are later read under, so they
+    // need no initial value and the predicated-off lanes need no zero fill.
     float s1_u1[4], s1_u2[4], s1_wx[4], s1_wy[4], s1_r[4], s1_11[4], s1_12[4], s1_21[4], s1_22[4];   // stage1 -> stage2
     float s2_u1[4], s2_u2[4], s2_11[4], s2_12[4], s2_21[4], s2_22[4];                                  // stage2 -> stage3
 #pragma unroll
@@ -854,7 +1002,13 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         s2_u1[i] = s2_u2[i] = s2_11[i] = s2_12[i] = s2_21[i] = s2_22[i] = 0.f;
     }
     bool s1_valid = false, s2_valid = false;
+    // column masks: inw[j] = all-ones iff column x + j lies inside the image (j = 0..4; x itself always does)
+    unsigned inw[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) inw[j] = opaque_u(x + j < W ? ~0u : 0u);
+    int ring = ty + 1;                                    // (r2 mod RB) for r2 = (s-1)*RY + ty, kept incrementally
     u64 qA = 0, qB = 0;
+    double accA = 0.0, accB = 0.0;
 
     for (int s = 0; s < ngroups + 2; ++s) {
         // ================= stage 1: group s, iteration `it` primal =================
@@ -886,16 +1040,15 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
             UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
             qu.l11 = l11; qu.l21 = l21;
             const bool isout = y >= y0 && y <= yout_hi;
-            tv_u_quad(a.l_t, a.theta, qu, y == 0, x == 0, n_u1, n_u2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (!replay && isout && x + i < W) qA += tv_err_q(n_u1[i], qu.u1k[i], n_u2[i], qu.u2k[i]);
+            tv_u_quad_pk(a.l_t, a.theta, qu, y == 0, x == 0, n_u1, n_u2);
+            const unsigned mrow = opaque_u(!replay && isout ? ~0u : 0u);
+            const unsigned keep[4] = {inw[0] & mrow, inw[1] & mrow, inw[2] & mrow, inw[3] & mrow};
+            accA += tv_err_quad_pk(n_u1, qu.u1k, n_u2, qu.u2k, keep);
             st4(U1a + ((s & 1) * RY + ty) * LW + x, PACK4(n_u1));
             st4(U1b + ((s & 1) * RY + ty) * LW + x, PACK4(n_u2));
         }
         __syncthreads();
         // ================= stage 2: group s-1: iteration `it` dual, then `it+1` primal =================
-        const int r2 = r1 - RY;
         const int yb = y - RY;
         const bool v2 = s1_valid && yb <= yp1_hi;           // s1_valid already implies in-image and >= yu1_lo
         float p1_11[4] = {0, 0, 0, 0}, p1_12[4] = {0, 0, 0, 0}, p1_21[4] = {0, 0, 0, 0}, p1_22[4] = {0, 0, 0, 0};
@@ -910,18 +1063,18 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
             }
             float rr1 = 0.f, rr2 = 0.f;
             if (x + 4 < W) { rr1 = U1a[(bp * RY + ty) * LW + x + 4]; rr2 = U1b[(bp * RY + ty) * LW + x + 4]; }
+            const unsigned mnl = opaque_u(lastrow ? 0u : ~0u);
             float dv1[4], dv2[4], u1x[4], u1y[4], u2x[4], u2y[4];
             UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int xi = x + i;
                 const float e1 = i < 3 ? s1_u1[i + 1] : rr1, e2 = i < 3 ? s1_u2[i + 1] : rr2;
-                u1x[i] = xi < W - 1 ? e1 - s1_u1[i] : 0.f;
-                u2x[i] = xi < W - 1 ? e2 - s1_u2[i] : 0.f;
-                u1y[i] = !lastrow ? dv1[i] - s1_u1[i] : 0.f;
-                u2y[i] = !lastrow ? dv2[i] - s1_u2[i] : 0.f;
+                u1x[i] = mask_f(e1 - s1_u1[i], inw[i + 1]);       // 0 in the last column (x + i == W - 1) and beyond
+                u2x[i] = mask_f(e2 - s1_u2[i], inw[i + 1]);
+                u1y[i] = mask_f(dv1[i] - s1_u1[i], mnl);          // 0 in the last row
+                u2y[i] = mask_f(dv2[i] - s1_u2[i], mnl);
             }
-            tv_p_quad(a.taut, u1x, u1y, u2x, u2y, s1_11, s1_12, s1_21, s1_22, p1_11, p1_12, p1_21, p1_22);
+            tv_p_quad_pk(a.taut, u1x, u1y, u2x, u2y, s1_11, s1_12, s1_21, s1_22, p1_11, p1_12, p1_21, p1_22);
             if (replay) {
                 if (yb >= y0 && yb <= yout_hi) {
                     const size_t prow = (size_t)yb * pitch + x;
@@ -930,8 +1083,8 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
                     st4(o21 + prow, PACK4(p1_21)); st4(o22 + prow, PACK4(p1_22));
                 }
             } else {
-                st4(B12 + (((r2 % RB) + RB) % RB) * LW + x, PACK4(p1_12));
-                st4(B22 + (((r2 % RB) + RB) % RB) * LW + x, PACK4(p1_22));
+                st4(B12 + ring * LW + x, PACK4(p1_12));
+                st4(B22 + ring * LW + x, PACK4(p1_22));
                 B11w[ty * QX + tx] = p1_11[3];
                 B21w[ty * QX + tx] = p1_21[3];
             }
@@ -944,7 +1097,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
             if (v2u) {
                 float4 up12 = make_float4(0, 0, 0, 0), up22 = up12;
                 if (yb > 0) {
-                    const int ri = (((r2 - 1) % RB) + RB) % RB;
+                    const int ri = ring > 0 ? ring - 1 : RB - 1;        // (r2 - 1) mod RB
                     up12 = ld4(B12 + ri * LW + x); up22 = ld4(B22 + ri * LW + x);
                 }
                 float l11 = 0.f, l21 = 0.f;
@@ -958,10 +1111,10 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
                 UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
                 qu.l11 = l11; qu.l21 = l21;
                 const bool isout = yb <= yout_hi;
-                tv_u_quad(a.l_t, a.theta, qu, yb == 0, x == 0, m_u1, m_u2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (isout && x + i < W) qB += tv_err_q(m_u1[i], s1_u1[i], m_u2[i], s1_u2[i]);
+                tv_u_quad_pk(a.l_t, a.theta, qu, yb == 0, x == 0, m_u1, m_u2);
+                const unsigned mrow = opaque_u(isout ? ~0u : 0u);
+                const unsigned keep[4] = {inw[0] & mrow, inw[1] & mrow, inw[2] & mrow, inw[3] & mrow};
+                accB += tv_err_quad_pk(m_u1, s1_u1, m_u2, s1_u2, keep);
                 st4(U2a + (((s - 1) & 1) * RY + ty) * LW + x, PACK4(m_u1));
                 st4(U2b + (((s - 1) & 1) * RY + ty) * LW + x, PACK4(m_u2));
             }
@@ -979,18 +1132,18 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
                 }
                 float rr1 = 0.f, rr2 = 0.f;
                 if (x + 4 < W) { rr1 = U2a[(bq * RY + ty) * LW + x + 4]; rr2 = U2b[(bq * RY + ty) * LW + x + 4]; }
+                const unsigned mnl = opaque_u(lastrow ? 0u : ~0u);
                 float dv1[4], dv2[4], r11[4], r12[4], r21[4], r22[4], u1x[4], u1y[4], u2x[4], u2y[4];
                 UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int xi = x + i;
                     const float e1 = i < 3 ? s2_u1[i + 1] : rr1, e2 = i < 3 ? s2_u2[i + 1] : rr2;
-                    u1x[i] = xi < W - 1 ? e1 - s2_u1[i] : 0.f;
-                    u2x[i] = xi < W - 1 ? e2 - s2_u2[i] : 0.f;
-                    u1y[i] = !lastrow ? dv1[i] - s2_u1[i] : 0.f;
-                    u2y[i] = !lastrow ? dv2[i] - s2_u2[i] : 0.f;
+                    u1x[i] = mask_f(e1 - s2_u1[i], inw[i + 1]);
+                    u2x[i] = mask_f(e2 - s2_u2[i], inw[i + 1]);
+                    u1y[i] = mask_f(dv1[i] - s2_u1[i], mnl);
+                    u2y[i] = mask_f(dv2[i] - s2_u2[i], mnl);
                 }
-                tv_p_quad(a.taut, u1x, u1y, u2x, u2y, s2_11, s2_12, s2_21, s2_22, r11, r12, r21, r22);
+                tv_p_quad_pk(a.taut, u1x, u1y, u2x, u2y, s2_11, s2_12, s2_21, s2_22, r11, r12, r21, r22);
                 const size_t prow = (size_t)yc * pitch + x;
                 st4(ou1 + prow, PACK4(s2_u1)); st4(ou2 + prow, PACK4(s2_u2));
                 st4(o11 + prow, PACK4(r11)); st4(o12 + prow, PACK4(r12));
@@ -1007,8 +1160,11 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
             s1_11[i] = c11[i]; s1_12[i] = c12[i]; s1_21[i] = c21[i]; s1_22[i] = c22[i];
         }
         s1_valid = v1;
+        ring += RY; ring = ring >= RB ? ring - RB : ring;
+        if ((s & 255) == 255) { qA += (u64)accA; qB += (u64)accB; accA = accB = 0.0; }   // keep the double sums exact
     }
     if (!replay) {
+        qA += (u64)accA; qB += (u64)accB;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { qA += __shfl_down(qA, off, 64); qB += __shfl_down(qB, off, 64); }
         __syncthreads();

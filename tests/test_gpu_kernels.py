@@ -104,6 +104,49 @@ def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
         engine.set_tuning("min_rows_work", 4096)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant):
+    """The dual/primal updates where real echo frames put them: next to exactly-black regions the flow and the dual
+    variable decay geometrically through 1e-30 into the denormal range.  State, warp constants and rho are scaled by
+    10^-k with k up to 44 per 8-px column band, with patches of +0 and -0; results are compared as BIT PATTERNS (so
+    the sign of zero and every denormal count)."""
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = 96, 384
+    rng = np.random.default_rng(21)
+    k = (np.arange(w) // 8).astype(np.float64)                       # 0 .. 47
+    sc = (10.0 ** -k)[None, :]
+    def scaled(lo, hi, s):
+        return (rng.uniform(lo, hi, (h, w)) * s).astype(np.float32)
+    u1, u2 = scaled(-1, 1, sc), scaled(-1, 1, sc)
+    p = [scaled(-0.5, 0.5, sc) for _ in range(4)]
+    wx, wy = scaled(-20, 20, np.sqrt(sc)), scaled(-20, 20, np.sqrt(sc))
+    rho = scaled(-3, 3, sc)
+    for a in (u1, u2, *p, wx, wy, rho):
+        a[10:20, :] = 0.0
+        a[30:34, :] = -0.0
+    wx[40:50] = rng.uniform(-20, 20, (10, w)).astype(np.float32)     # ordinary gradients over tiny flow
+    wy[40:50] = rng.uniform(-20, 20, (10, w)).astype(np.float32)
+    grad = wx * wx + wy * wy
+    engine.set_tuning("iter_variant", variant)
+    engine.set_tuning("min_rows_work", 0)
+    try:
+        nsteps = 6
+        ref = oracle.iterate(wx, wy, grad, rho, u1, u2, *p, nsteps)
+        st = [a.copy() for a in (u1, u2, *p)]
+        err = np.zeros(nsteps, np.uint64)
+        _lib.check(L.tf_dbg_iterate(engine._h, _ptr(wx), _ptr(wy), _ptr(rho), *[_ptr(a) for a in st], w, h, nsteps, 0,
+                                    _ptr(err)), engine._h)
+    finally:
+        engine.set_tuning("iter_variant", 2)
+        engine.set_tuning("min_rows_work", 4096)
+    for n, a, r in zip(["u1", "u2", "p11", "p12", "p21", "p22"], st, ref[:6]):
+        bad = a.view(np.uint32) != r.view(np.uint32)
+        assert not bad.any(), f"{n}: {bad.sum()} bit patterns differ, first at {np.argwhere(bad)[0]}: {a[bad][0]!r} vs {r[bad][0]!r}"
+    assert np.array_equal(err, ref[6])
+    assert np.any((np.abs(ref[2]) < 1e-38) & (ref[2] != 0)), "case no longer reaches the denormal range"
+
+
 def _iterate_case(engine, oracle, L, shape, pzero):
     from tee_optical_flow_amd import _lib
     h, w = shape

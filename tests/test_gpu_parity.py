@@ -177,6 +177,25 @@ def test_tiny_images(oracle):
     eng.close()
 
 
+def test_echo_like_sector_with_black_background(engine, oracle):
+    """Real TEE frames are a bright sector on an exactly-black background (zero image gradient: the flow there is pure
+    TV diffusion from the sector).  Full solve, bit patterns compared (zero signs included)."""
+    from tee_optical_flow_amd.synth import speckle_pair
+    H, W = 192, 256
+    I0, I1, _ = speckle_pair(31, H, W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ang = np.arctan2(xx - W / 2, yy + 8.0)
+    sector = (np.abs(ang) < 0.6) & (np.hypot(xx - W / 2, yy + 8.0) < H * 0.95)
+    I0 = np.where(sector, I0, 0).astype(np.uint8)
+    I1 = np.where(sector, I1, 0).astype(np.uint8)
+    ref, ref_it, _ = oracle.tvl1_calc(I0, I1, return_iters=True)
+    out = engine.calc(I0, I1, None)
+    nl = engine.last_iters().shape[1]
+    assert np.array_equal(engine.last_iters()[0], ref_it[:nl])
+    bad = np.ascontiguousarray(out).view(np.uint32) != np.ascontiguousarray(ref).view(np.uint32)
+    assert not bad.any(), f"{bad.sum()} bit patterns differ, e.g. {out[bad][:3]!r} vs {ref[bad][:3]!r}"
+
+
 def test_symmetries(engine):
     """SURVEY.md 8c item 3 (behavioural KATs on the GPU path itself): transpose swaps (u,v)."""
     from tee_optical_flow_amd.synth import speckle_pair

@@ -47,6 +47,8 @@ def main():
                 ref = f
             same = bool(np.array_equal(ref, f))
             res[c].append((dt * 1e3, st["iter_ms"], st["iter_bytes"] / 1e9 / (st["iter_ms"] / 1e3), st["iter_launches"], same))
+    import hashlib
+    print("lib", os.environ.get("TEEFLOW_LIB", "default"), "flow sha1", hashlib.sha1(ref.tobytes()).hexdigest()[:16])
     for c, v in res.items():
         v = np.array(v, dtype=np.float64)
         print(f"{c:45s} step ms med {np.median(v[:,0]):8.2f} min {v[:,0].min():8.2f} | iter ms med {np.median(v[:,1]):8.2f} "
