@@ -266,7 +266,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     // short strips (latency of a few steps) instead of a few long ones
     strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
     const int LW = QX * 4 + 4;
-    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
+    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 2 * RY * QX) * sizeof(float);
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY);
 }
 

@@ -947,9 +947,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     float* B12 = U2b + 2 * RY * LW;                // [RY+1][LW]   rolling rows of p1_12 / p1_22 (p0's row above is
                                                    //              re-read from global/L2: keeps LDS at 3 blocks per CU)
     float* B22 = B12 + (RY + 1) * LW;
-    float* A11w = B22 + (RY + 1) * LW;             // [RY][QX]     last element of each quad of p0_11 / p0_21
-    float* A21w = A11w + RY * QX;
-    float* B11w = A21w + RY * QX;                  //              ... of p1_11 / p1_21
+    float* B11w = B22 + (RY + 1) * LW;             // [RY][QX]     last element of each quad of p1_11 / p1_21
     float* B21w = B11w + RY * QX;
 
     publish_active_count2(A);
@@ -1022,18 +1020,17 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
             u1q = ld4(gu1 + row); u2q = ld4(gu2 + row);
             wxq = ld4(gwx + row); wyq = ld4(gwy + row); rq = ld4(grh + row);
             if (!pzero) { a11 = ld4(g11 + row); a12 = ld4(g12 + row); a21 = ld4(g21 + row); a22 = ld4(g22 + row); }
-            A11w[ty * QX + tx] = a11.w;
-            A21w[ty * QX + tx] = a21.w;
         }
-        __syncthreads();
         float n_u1[4] = {0, 0, 0, 0}, n_u2[4] = {0, 0, 0, 0};
         float c11[4], c12[4], c21[4], c22[4], wxv[4], wyv[4], rv[4];
         UNPACK4(c11, a11) UNPACK4(c12, a12) UNPACK4(c21, a21) UNPACK4(c22, a22) UNPACK4(wxv, wxq) UNPACK4(wyv, wyq) UNPACK4(rv, rq)
         if (v1) {
             float4 up12 = make_float4(0, 0, 0, 0), up22 = up12;
             if (y > 0 && !pzero) { up12 = ld4(g12 + row - pitch); up22 = ld4(g22 + row - pitch); }
+            // dual variable of the pixel left of the quad: one dword each straight from global memory (the line is in
+            // L1/L2, the neighbouring lane loads it as part of its float4) -- no LDS exchange, no barrier
             float l11 = 0.f, l21 = 0.f;
-            if (tx > 0) { l11 = A11w[ty * QX + tx - 1]; l21 = A21w[ty * QX + tx - 1]; }
+            if (tx > 0 && !pzero) { l11 = g11[row - 1]; l21 = g21[row - 1]; }
             QuadU qu;
             UNPACK4(qu.u1k, u1q) UNPACK4(qu.u2k, u2q) UNPACK4(qu.wx, wxq) UNPACK4(qu.wy, wyq) UNPACK4(qu.r, rq)
             UNPACK4(qu.p11, a11) UNPACK4(qu.p12, a12) UNPACK4(qu.p21, a21) UNPACK4(qu.p22, a22)
