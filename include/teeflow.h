@@ -174,6 +174,12 @@ int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);
 int tf_dbg_df_blur(tf_handle* h, const float* src, int w, int hgt, float* dst);
+/* per-launch record of the last solve run with tf_set_profile(h, 1): tvl1_iter launches in issue order (single lane);
+ * returns the number of records, fills at most max_n */
+int tf_dbg_launch_profile(tf_handle* h, int* level, int* warp, int* it, float* ms, int max_n);
+/* strip sizing rule of the tvl1_iter kernel (host arithmetic only): rows per strip R (multiple of RY) and strip count S
+ * for n_active pairs still iterating on a device with `slots` resident blocks */
+void tf_dbg_strip_rule(int n_active, int H, int RY, int slots, int* R, int* S);
 int tf_dbg_pyramid(tf_handle* h, const uint8_t* img, int H, int W, int level, float* out, int* ow, int* oh);
 int tf_dbg_resize(tf_handle* h, const float* src, int sw, int sh, float* dst, int dw, int dh,
                   double inv_scale_x, double inv_scale_y, float mul);

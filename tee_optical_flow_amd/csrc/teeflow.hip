@@ -23,6 +23,7 @@
 #include <deque>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #define TF_API extern "C" __attribute__((visibility("default")))
@@ -37,7 +38,7 @@ constexpr int DEFAULT_MAX_BATCH = 128;
 
 thread_local std::string g_create_error;
 
-struct ProfEv { hipEvent_t a, b; };
+struct ProfEv { hipEvent_t a, b; int level = 0, warp = 0, it = 0; float ms = 0.f; };
 
 }  // namespace
 
@@ -89,6 +90,9 @@ struct tf_handle {
                                  // while one lane runs the thin tail of a stage, the other fills the GPU (+6 % measured; 4 lanes lose)
     tf_handle* twin = nullptr; bool is_twin = false;
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
+    int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
+    int slots_override = 0, num_cus = 256;
+    std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
     int sor_fuse = 3;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 3 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
@@ -267,7 +271,29 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
     const int LW = QX * 4 + 4;
     const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 2 * RY * QX) * sizeof(float);
-    hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY);
+    if (h->dynamic_strips && B <= 1024) {
+        // strips sized on the device from the exact number of pairs still iterating; the grid covers the largest item count
+        int slots = h->slots_override;
+        if (slots <= 0) {
+            auto f = h->slots_cache.find(shmem * 1024 + (size_t)threads / 64);
+            if (f == h->slots_cache.end()) {
+                int per_cu = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iter2_rows, threads, shmem);
+                if (per_cu < 1) per_cu = 1;
+                f = h->slots_cache.emplace(shmem * 1024 + (size_t)threads / 64, per_cu * h->num_cus).first;
+            }
+            slots = f->second;
+        }
+        int items = 1;
+        for (int n = 1; n <= B; ++n) {
+            int r, sn;
+            strip_rule(n, g.h, RY, slots, &r, &sn);
+            if (n * sn > items) items = n * sn;
+        }
+        hipLaunchKernelGGL(k_iter2_rows, dim3(items, 1, 1), dim3(threads), shmem, s, A, 0, QX, RY, slots);
+        return;
+    }
+    hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
 }
 
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
@@ -357,6 +383,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
                     h->prof_pool.push_back(pe);
                 }
                 ProfEv& pe = h->prof_pool[h->prof_used++];
+                pe.level = l; pe.warp = wi; pe.it = it;
                 HIPC(h, hipEventRecord(pe.a, s));
                 launch_iter2(h, A2, B, s, last_active);
                 HIPC(h, hipEventRecord(pe.b, s));
@@ -408,6 +435,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
                 h->prof_pool.push_back(pe);
             }
             ProfEv& pe = h->prof_pool[h->prof_used++];
+            pe.level = l; pe.warp = wi; pe.it = it;
             HIPC(h, hipEventRecord(pe.a, s));
             launch_iter(h, ia, B, s);
             HIPC(h, hipEventRecord(pe.b, s));
@@ -739,6 +767,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         for (size_t i = 0; i < h->prof_used; ++i) {
             float t = 0;
             HIPC(h, hipEventElapsedTime(&t, h->prof_pool[i].a, h->prof_pool[i].b));
+            h->prof_pool[i].ms = t;
             ims += t;
         }
         st->iter_ms = ims;
@@ -763,6 +792,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     t->P = h->P; t->DP = h->DP; t->profile = h->profile;
     t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
     t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
+    t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
     const size_t fpx = (size_t)H * W;
     const int nA = n_pairs / 2, nB = n_pairs - nA;
     const uint8_t* b0 = mode == MODE_SEQ ? in0 + (size_t)nA * fpx : in0 + (size_t)nA * fpx;      // SEQ: frames nA..n_pairs (1-frame overlap)
@@ -879,6 +909,10 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter2_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
@@ -993,11 +1027,37 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
+    else if (n == "dynamic_strips") h->dynamic_strips = value;
+    else if (n == "slots") h->slots_override = value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 2 ? 2 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
+}
+
+// the strip rule of k_iter2_rows (pure host arithmetic, no device call): rows per strip and strip count for n active pairs
+TF_API void tf_dbg_strip_rule(int n_active, int H, int RY, int slots, int* R, int* S)
+{
+    int r = 0, sn = 0;
+    strip_rule(n_active, H, RY, slots, &r, &sn);
+    if (R) *R = r;
+    if (S) *S = sn;
+}
+
+// per-launch record of the last profiled solve (tvl1_iter launches in issue order): level, warp, first iteration, ms
+TF_API int tf_dbg_launch_profile(tf_handle* h, int* level, int* warp, int* it, float* ms, int max_n)
+{
+    if (!h) return -1;
+    const int n = (int)std::min<size_t>(h->prof_used, (size_t)std::max(max_n, 0));
+    for (int i = 0; i < n; ++i) {
+        const ProfEv& pe = h->prof_pool[i];
+        if (level) level[i] = pe.level;
+        if (warp) warp[i] = pe.warp;
+        if (it) it[i] = pe.it;
+        if (ms) ms[i] = pe.ms;
+    }
+    return (int)h->prof_used;
 }
 
 TF_API int tf_set_profile(tf_handle* h, int level)

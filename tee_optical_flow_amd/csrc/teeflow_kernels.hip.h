@@ -914,6 +914,24 @@ __device__ __forceinline__ int pair_mode2(const u64* e, int it, int total, doubl
     return M_EXIT;
 }
 
+// Work items of a tvl1_iter launch when the strips are sized ON THE DEVICE from the number of pairs that still
+// iterate (`n`): one round of at most `slots` resident blocks (slots = CUs x blocks per CU), each marching a strip that is
+// as long as that allows -- a lock-step batch loses a third of its time otherwise (a launch with 1024 blocks on 768 slots
+// takes two rounds, one with 300 takes as long as one with 768).  Returns rows per strip (a multiple of RY) and the strip count.
+TF_HD inline void strip_rule(int n, int H, int RY, int slots, int* R, int* S)
+{
+    if (n < 1) n = 1;
+    const int k = (n + slots - 1) / slots;                 // rounds
+    int s = (int)(((long long)k * slots) / n);
+    const int smax = H / (4 * RY) > 0 ? H / (4 * RY) : 1;  // at least 4 steps per strip (3 halo rows each)
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    int r = (H + s - 1) / s;
+    r = (r + RY - 1) / RY * RY;
+    *R = r;
+    *S = (H + r - 1) / r;
+}
+
 struct Iter2Args {
     IterArgs a;                           // a.it = first iteration of the launch (even), a.utog/ptog/pzero for it
     int utog_prev, ptog_prev, pzero_prev; // the same three for the previous launch (used by REPLAY blocks)
@@ -934,7 +952,9 @@ __device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
 }
 
 
-__global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, int RY)
+// `slots` > 0: grid = (max work items, 1, 1) and every block finds its (pair, strip) among the pairs that still iterate;
+// `slots` == 0: grid = (strips, 1, pairs) with the fixed strip length R.
+__global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, int RY, int slots)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IterArgs& a = A.a;
@@ -951,7 +971,32 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     float* B21w = B11w + RY * QX;
 
     publish_active_count2(A);
-    const int b = blockIdx.z;
+    int b = blockIdx.z, strip = blockIdx.x;
+    if (slots > 0) {
+        // 64-pair masks of the pairs that are not in EXIT mode (sred is free until the end of the kernel; B <= 1024)
+        const int nchunk = (a.B + 63) >> 6, nw = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+        for (int c = wv; c < nchunk; c += nw) {
+            const int pb = c * 64 + ln;
+            const bool on = pb < a.B && pair_mode2(a.err + (size_t)pb * a.errstride, a.it, A.total, a.thr_q) != M_EXIT;
+            const u64 m = __ballot(on);
+            if (ln == 0) sred[c] = m;
+        }
+        __syncthreads();
+        int nact = 0;
+        for (int c = 0; c < nchunk; ++c) nact += __popcll(sred[c]);
+        int S;
+        strip_rule(nact, a.g.h, RY, slots, &R, &S);
+        const int item = blockIdx.x;
+        if (item >= nact * S) return;                      // block-uniform
+        int k = item / S;
+        strip = item - k * S;
+        int c = 0;
+        u64 m = sred[0];
+        while (k >= __popcll(m)) { k -= __popcll(m); m = sred[++c]; }
+        for (; k > 0; --k) m &= m - 1;                      // drop the k lowest set bits
+        b = c * 64 + (__ffsll((long long)m) - 1);
+        __syncthreads();                                    // sred is reused for the error sums below
+    }
     u64* errb = a.err + (size_t)b * a.errstride;
     const int mode = pair_mode2(errb, a.it, A.total, a.thr_q);   // block-uniform
     if (mode == M_EXIT) return;
@@ -965,7 +1010,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     const bool lane_on = ty < RY;
     const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
     const int x = tx * 4;
-    const int y0 = blockIdx.x * R;
+    const int y0 = strip * R;
     const int n = R / RY;
     const int ngroups = n + 2 + (RY == 1 ? 1 : 0);
     const size_t po = (size_t)b * a.g.splane;
