@@ -197,10 +197,11 @@ def main():
             ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<3> (red-black SOR, 3 sweeps per launch on LDS tiles; dominant)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms, "launches": acc["iter_launches"],
-                    "bytes_per_px_sweep": 80,
-                    "note": "achieved = executed pixel-sweeps x 80 B (the one-colour-per-launch form's traffic: 8 plane reads + 2 writes per "
-                            "colour pass) / summed launch time, one HIP event pair per launch, single lane; the fused kernel moves about a "
-                            "third of that through HBM"}
+                    "bytes_per_px_sweep": 40,
+                    "note": "achieved = executed pixel-sweeps x 40 B (compulsory traffic of ONE red-black sweep: du, dv, weight, A11, A12, "
+                            "A22, b1, b2 read, du, dv written) / summed launch time, one HIP event pair per launch, single lane; the kernel "
+                            "fuses 3 sweeps per launch on LDS tiles, so about a third of that goes through HBM and the kernel is bound by "
+                            "LDS latency and the two IEEE divisions per update"}
         out = {
             "metric": "frame-pairs/sec @512x512 " + ("DualTVL1" if a.algo == "TVL1" else "DeepFlow"), "value": pairs / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -71,7 +71,7 @@ struct tf_handle {
     std::vector<int> last_iters; int last_pairs = 0, last_nlev = 0, last_warps = 0;
     // per-call accumulators
     unsigned long long iter_launches = 0;
-    double df_sor_bytes = 0;     // DeepFlow: algorithmic bytes of the SOR launches of the current call (80 B per pixel-sweep)
+    double df_sor_bytes = 0;     // DeepFlow: algorithmic bytes of the SOR launches of the current call (40 B per pixel-sweep)
     // ---- DeepFlow (algo == TF_ALGO_DEEPFLOW) ----
     tf_deepflow_params DP = {};
     int dnlev = 0, dH = 0, dW = 0, dcap = 0;
@@ -629,7 +629,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
                 if (h->prof_used < h->prof_pool.size()) { pe = &h->prof_pool[h->prof_used++]; (void)hipEventRecord(pe->a, s); }
             }
             ++h->iter_launches;
-            h->df_sor_bytes += (double)n * g.w * g.h * B * 80.0;
+            h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;   // one sweep: 8 planes read + du, dv written
             switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
                 case 1: launch_sor_fused<1>(d, g, B, c.omega, s); break;
                 case 2: launch_sor_fused<2>(d, g, B, c.omega, s); break;
