@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--tuning", default="", help="experiments only: engine knobs as name=value,... (tf_set_tuning); empty = shipped defaults")
     a = ap.parse_args()
 
     import torch
@@ -110,6 +111,9 @@ def main():
     gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
     eng = T.DenseFlow(device_id=local_rank, max_batch=B, algo=a.algo)
     eng.set_tuning("lanes", a.lanes)
+    tuning = [kv.split("=") for kv in a.tuning.split(",") if kv]
+    for k, v in tuning:
+        eng.set_tuning(k, int(v))
     # the engine runs on its own non-blocking HIP stream (its per-launch events are recorded there); every call is
     # host-synchronous, so torch-side consumers (the RCCL all-gather) may start right after it returns
     p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
@@ -221,6 +225,8 @@ def main():
         }
         # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
         lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1, algo=a.algo)
+        for k, v in tuning:
+            lat_eng.set_tuning(k, int(v))
         f1 = torch.empty((1, H, W, 2), dtype=torch.float32, device=dev)
         for _ in range(3):
             lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())

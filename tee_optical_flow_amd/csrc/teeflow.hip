@@ -33,7 +33,7 @@ namespace {
 constexpr int MAXLEV = 64;
 constexpr int DF_MAXLEV = 160;       // x0.95 pyramid: 60 levels at 512^2, 87 at 2048^2
 constexpr int SLOT_RING = 1024;       // host-mapped words the tvl1_iter launches publish their active-pair count to
-constexpr int DEFAULT_LAG = 3;        // the host enqueues at most this many launches beyond the last answer it has read
+constexpr int DEFAULT_LAG = 1;        // the host enqueues at most this many launches beyond the last answer it has read
 constexpr int DEFAULT_MAX_BATCH = 128;
 
 thread_local std::string g_create_error;
