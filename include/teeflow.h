@@ -174,6 +174,16 @@ int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);
 int tf_dbg_df_blur(tf_handle* h, const float* src, int w, int hgt, float* dst);
+/* "WASE" background compensation (rows a7/f2), replaces the numpy expression of
+ * /root/reference/optical_flow/calculate_optical_flow.py:647-652, 659 for ALL flows of a study in one call:
+ *   background[p] = np.mean(masked[masked != 0]),  masked = flows[p] * bkgd      (bkgd: bool [n_frames][H][W][2], 0/1 bytes)
+ *   flows[p] = (flows[p] - background[p]) * scale                                  (in place)
+ * The float32 reduction follows numpy's summation order exactly (8192-element pieces, pairwise sums, float64 divide).
+ * tf_wase_compensate takes host pointers, the _device form device pointers; background_out (host, n_flows) may be NULL. */
+int tf_wase_compensate(tf_handle* h, float* flows, int n_flows, const uint8_t* bkgd, int n_frames, int H, int W, float scale,
+                       float* background_out);
+int tf_wase_compensate_device(tf_handle* h, float* flows, int n_flows, const uint8_t* bkgd, int n_frames, int H, int W, float scale,
+                              float* background_out);
 /* per-launch record of the last solve run with tf_set_profile(h, 1): tvl1_iter launches in issue order (single lane);
  * returns the number of records, fills at most max_n */
 int tf_dbg_launch_profile(tf_handle* h, int* level, int* warp, int* it, float* ms, int max_n);

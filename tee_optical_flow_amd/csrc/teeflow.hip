@@ -13,6 +13,7 @@
 #include "teeflow_kernels.hip.h"
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_analysis.hip.h"
+#include "teeflow_wase.hip.h"
 #include "../../include/teeflow.h"
 
 #include <chrono>
@@ -92,6 +93,11 @@ struct tf_handle {
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
+    // WASE scratch (grown on demand): compacted products, block counts / offsets, piece sums, per-flow backgrounds
+    float* wa = nullptr; size_t wa_cap = 0;
+    unsigned* wcnt = nullptr; u64* woff = nullptr; size_t wcnt_cap = 0;
+    float* wsum = nullptr; size_t wsum_cap = 0;
+    float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
     int sor_fuse = 3;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 3 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
@@ -957,6 +963,11 @@ TF_API void tf_destroy(tf_handle* h)
     if (h->slots_host) (void)hipHostFree((void*)h->slots_host);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& pe : h->prof_pool) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    if (h->wa) (void)hipFree(h->wa);
+    if (h->wcnt) (void)hipFree(h->wcnt);
+    if (h->woff) (void)hipFree(h->woff);
+    if (h->wsum) (void)hipFree(h->wsum);
+    if (h->wbg) (void)hipFree(h->wbg);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1247,6 +1258,93 @@ TF_API int tf_radlong_select(tf_handle* h, int which, const long long* ranks, do
     (void)hipFree(pf); (void)hipFree(rk); (void)hipFree(ac); (void)hipFree(hist);
     if (e != hipSuccess) return fail(h, TF_ERR_HIP, "tf_radlong_select: %s", hipGetErrorString(e));
     for (int i = 0; i < NS; ++i) values_out[i] = act[i] ? f64_unkey(keys[i]) : 0.0;
+    return TF_OK;
+}
+
+// ---- WASE background compensation (rows a7 / f2) ---------------------------------------------------------------
+namespace {
+int wase_grow(tf_handle* h, size_t na, size_t ncnt, size_t nsum, size_t nbg)
+{
+    if (h->wa_cap < na) { if (h->wa) (void)hipFree(h->wa); h->wa = nullptr; h->wa_cap = 0; HIPC(h, hipMalloc(&h->wa, na * sizeof(float))); h->wa_cap = na; }
+    if (h->wcnt_cap < ncnt) {
+        if (h->wcnt) (void)hipFree(h->wcnt);
+        if (h->woff) (void)hipFree(h->woff);
+        h->wcnt = nullptr; h->woff = nullptr; h->wcnt_cap = 0;
+        HIPC(h, hipMalloc(&h->wcnt, ncnt * sizeof(unsigned))); HIPC(h, hipMalloc(&h->woff, (ncnt + 1) * sizeof(u64)));
+        h->wcnt_cap = ncnt;
+    }
+    if (h->wsum_cap < nsum) { if (h->wsum) (void)hipFree(h->wsum); h->wsum = nullptr; h->wsum_cap = 0; HIPC(h, hipMalloc(&h->wsum, nsum * sizeof(float))); h->wsum_cap = nsum; }
+    if (h->wbg_cap < nbg) { if (h->wbg) (void)hipFree(h->wbg); h->wbg = nullptr; h->wbg_cap = 0; HIPC(h, hipMalloc(&h->wbg, nbg * sizeof(float))); h->wbg_cap = nbg; }
+    return TF_OK;
+}
+
+// flows, bkgd: device.  Leaves the backgrounds in h->wbg[0..P) and (if apply) the compensated, scaled flows in place.
+int wase_device(tf_handle* h, float* flows, const uint8_t* bkgd, int P, int N, int H, int W, float scale, bool apply)
+{
+    const size_t hw2 = (size_t)H * W * 2;
+    const int C = (int)((hw2 + WASE_CHUNK - 1) / WASE_CHUNK);
+    const size_t ncnt = (size_t)N * C, na = (size_t)N * hw2, npieces = (na + NP_BUFSIZE - 1) / NP_BUFSIZE;
+    int rc = wase_grow(h, na, ncnt, npieces, (size_t)P);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    for (int p = 0; p < P; ++p) {
+        const float* f = flows + (size_t)p * hw2;
+        hipLaunchKernelGGL(k_wase_count, dim3(C, N), dim3(256), 0, s, f, bkgd, hw2, C, h->wcnt);
+        hipLaunchKernelGGL(k_wase_scan, dim3(1), dim3(1024), 0, s, h->wcnt, ncnt, h->woff);
+        hipLaunchKernelGGL(k_wase_scatter, dim3(C, N), dim3(256), 0, s, f, bkgd, hw2, C, h->woff, h->wa);
+        hipLaunchKernelGGL(k_wase_piece_sums, dim3((unsigned)npieces), dim3(512), 0, s, h->wa, h->woff + ncnt, h->wsum);
+        hipLaunchKernelGGL(k_wase_finish, dim3(1), dim3(64), 0, s, h->wsum, h->woff + ncnt, h->wbg + p);
+    }
+    if (apply) {
+        const unsigned gx = (unsigned)std::min<size_t>((hw2 + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_wase_apply, dim3(gx, P), dim3(256), 0, s, flows, h->wbg, hw2, scale);
+    }
+    HIPC(h, hipGetLastError());
+    return TF_OK;
+}
+}  // namespace
+
+TF_API int tf_wase_compensate_device(tf_handle* h, float* flows, int n_flows, const uint8_t* bkgd, int n_frames, int H, int W, float scale,
+                                     float* background_out)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!flows || !bkgd || n_flows < 1 || n_frames < 1 || H < 1 || W < 1) return fail(h, TF_ERR_INVALID_ARG, "tf_wase_compensate: bad argument");
+    HIPC(h, hipSetDevice(h->dev));
+    int rc = wase_device(h, flows, bkgd, n_flows, n_frames, H, W, scale, true);
+    if (rc) return rc;
+    if (background_out) HIPC(h, hipMemcpyAsync(background_out, h->wbg, (size_t)n_flows * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return TF_OK;
+}
+
+TF_API int tf_wase_compensate(tf_handle* h, float* flows, int n_flows, const uint8_t* bkgd, int n_frames, int H, int W, float scale,
+                              float* background_out)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!flows || !bkgd || n_flows < 1 || n_frames < 1 || H < 1 || W < 1) return fail(h, TF_ERR_INVALID_ARG, "tf_wase_compensate: bad argument");
+    HIPC(h, hipSetDevice(h->dev));
+    const size_t hw2 = (size_t)H * W * 2;
+    float* df = nullptr; uint8_t* dm = nullptr;
+    HIPC(h, hipMalloc(&dm, (size_t)n_frames * hw2));
+    hipError_t e = hipMemcpyAsync(dm, bkgd, (size_t)n_frames * hw2, hipMemcpyHostToDevice, h->stream);
+    const int chunk = 64;                                   // flows per round trip
+    if (e == hipSuccess) e = hipMalloc(&df, (size_t)std::min(chunk, n_flows) * hw2 * sizeof(float));
+    int rc = TF_OK;
+    for (int p0 = 0; p0 < n_flows && e == hipSuccess && rc == TF_OK; p0 += chunk) {
+        const int np = std::min(chunk, n_flows - p0);
+        e = hipMemcpyAsync(df, flows + (size_t)p0 * hw2, (size_t)np * hw2 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) break;
+        rc = wase_device(h, df, dm, np, n_frames, H, W, scale, true);
+        if (rc) break;
+        e = hipMemcpyAsync(flows + (size_t)p0 * hw2, df, (size_t)np * hw2 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && background_out)
+            e = hipMemcpyAsync(background_out + p0, h->wbg, (size_t)np * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(df); (void)hipFree(dm);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "tf_wase_compensate: %s", hipGetErrorString(e));
     return TF_OK;
 }
 

@@ -177,6 +177,21 @@ class DenseFlow:
         self._finish(st)
         return out
 
+    def wase_compensate(self, flows, bkgd_mask, scale=1.0):
+        """Reference :647-652, 659 for every flow of a study at once, on the device: returns (flows - background[p]) * scale
+        and the float32 backgrounds.  flows float32 [P,H,W,2]; bkgd_mask bool [N,H,W,2] (mask_dict['bkgd'])."""
+        flows = np.array(flows, dtype=np.float32, order="C", copy=True)
+        mask = np.ascontiguousarray(bkgd_mask)
+        if flows.ndim != 4 or flows.shape[3] != 2:
+            raise OpticalFlowCalculationError(f"flows must be [P,H,W,2], got {flows.shape}")
+        if mask.dtype != np.bool_ or mask.ndim != 4 or mask.shape[1:] != flows.shape[1:]:
+            raise OpticalFlowCalculationError(f"bkgd mask must be bool [N,{flows.shape[1]},{flows.shape[2]},2], got {mask.dtype} {mask.shape}")
+        P, H, W, _ = flows.shape
+        bg = np.empty(P, np.float32)
+        _lib.check(self._L.tf_wase_compensate(self._h, flows.ctypes.data, P, mask.view(np.uint8).ctypes.data, mask.shape[0], H, W,
+                                              float(scale), bg.ctypes.data), self._h, "tf_wase_compensate")
+        return flows, bg
+
     def calc_pairs(self, I0s, I1s):
         """B independent pairs: uint8 [B,H,W] x2 -> float32 [B,H,W,2]."""
         I0s = _u8_image_stack(I0s, "I0s", 3)

@@ -72,7 +72,10 @@ def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conver
     else:
         flows = OF_model.calc_batch(frames_u8)                   # float32 [N-1,H,W,2]
     if bkgd_comp == "WASE":
-        flows = np.stack([_compensate(flows[i], mask_dict, "WASE") for i in range(flows.shape[0])])
+        if hasattr(OF_model, "wase_compensate"):                 # device: O(N^2 H W) products, numpy's summation order kept
+            flows, _ = OF_model.wase_compensate(flows, mask_dict["bkgd"])
+        else:
+            flows = np.stack([_compensate(flows[i], mask_dict, "WASE") for i in range(flows.shape[0])])
     flows = np.concatenate([flows, flows[-1:]], axis=0)          # copy last optical flow (:599)
     return flows * conversion_factor                              # (:600)
 
