@@ -260,7 +260,7 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
     if (ry < 1) ry = 1;
     if (h->force_ry > 0 && qx * h->force_ry <= 512) ry = h->force_ry;
     *QX = qx; *RY = ry;
-    *threads = qx * ry <= 256 ? 256 : (qx * ry + 63) / 64 * 64;
+    *threads = (qx * ry <= 256 && h->force_ry <= 0) ? 256 : (qx * ry + 63) / 64 * 64;   // forced shapes: no idle waves
     long long n = (long long)g.h * B / ((long long)h->strip_blocks * ry);
     if (n < 2) n = 2;
     if (n > 16) n = 16;
