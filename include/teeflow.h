@@ -174,6 +174,12 @@ int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);
 int tf_dbg_df_blur(tf_handle* h, const float* src, int w, int hgt, float* dst);
+/* Pinned host memory for flow results.  The reference gets a fresh numpy array from cv2 (`flow = OF_model.calc(...)`,
+ * calculate_optical_flow.py:631,642); handing tf_calc_pair/_seq/_pairs a destination from tf_host_alloc (or any pinned
+ * host pointer) lets the library copy results out at PCIe speed while the next sub-batch is being solved.  Pageable
+ * destinations work too, in order.  tf_host_alloc returns NULL on failure. */
+void* tf_host_alloc(size_t bytes);
+void  tf_host_free(void* p);
 /* "WASE" background compensation (rows a7/f2), replaces the numpy expression of
  * /root/reference/optical_flow/calculate_optical_flow.py:647-652, 659 for ALL flows of a study in one call:
  *   background[p] = np.mean(masked[masked != 0]),  masked = flows[p] * bkgd      (bkgd: bool [n_frames][H][W][2], 0/1 bytes)

@@ -11,6 +11,7 @@ not re-entrant, result owned by the caller.  Everything is computed by hand-writ
 C ABI in include/teeflow.h; there is no CPU path.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -27,6 +28,47 @@ def _u8_image_stack(a, name, ndim):
     return np.ascontiguousarray(a)
 
 
+class _PinnedPool:
+    """Result arrays backed by pinned host memory (tf_host_alloc): the library then copies flows out at PCIe speed while
+    the next sub-batch is still being solved.  A buffer returns to the pool when the numpy array that owns it is garbage
+    collected (the caller still gets a fresh array per call, like cv2), so a steady stream of equally sized calls
+    allocates nothing."""
+
+    def __init__(self, L, keep_bytes=2 << 30):
+        self._L, self._free, self._kept, self._keep = L, {}, 0, keep_bytes
+        self.closed = False
+
+    def empty(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if n == 0:
+            return np.empty(shape, dtype)
+        lst = self._free.get(n)
+        if lst:
+            ptr = lst.pop()
+            self._kept -= n
+        else:
+            ptr = self._L.tf_host_alloc(n)
+            if not ptr:
+                return np.empty(shape, dtype)            # pinning refused (limits): pageable memory still works
+        raw = (C.c_char * n).from_address(ptr)
+        weakref.finalize(raw, self._give_back, ptr, n).atexit = False    # at interpreter exit the process frees it
+        return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def _give_back(self, ptr, n):
+        if self.closed or self._kept + n > self._keep:
+            self._L.tf_host_free(ptr)
+        else:
+            self._free.setdefault(n, []).append(ptr)
+            self._kept += n
+
+    def close(self):
+        self.closed = True
+        for lst in self._free.values():
+            for ptr in lst:
+                self._L.tf_host_free(ptr)
+        self._free, self._kept = {}, 0
+
+
 class DenseFlow:
     """MI355X DualTVL1 solver with the cv2.DenseOpticalFlow calling convention."""
 
@@ -37,6 +79,7 @@ class DenseFlow:
 
     def __init__(self, device_id=0, max_batch=128, algo="TVL1", **params):
         self._L = _lib.load()
+        self._pool = _PinnedPool(self._L)
         self.algo = algo
         if algo == "deepflow":
             dp = _lib.TfDeepflowParams()
@@ -70,9 +113,15 @@ class DenseFlow:
 
     # ---- lifetime ------------------------------------------------------------------------------
     def close(self):
+        if getattr(self, "_pool", None):
+            self._pool.close()
         if getattr(self, "_h", None):
             self._L.tf_destroy(self._h)
             self._h = None
+
+    def _out(self, shape):
+        """A fresh float32 result array (pinned host memory from the pool)."""
+        return self._pool.empty(shape, np.float32)
 
     def __del__(self):
         try:
@@ -133,7 +182,7 @@ class DenseFlow:
         if I0.shape != I1.shape:
             raise OpticalFlowCalculationError(f"I0 and I1 sizes differ: {I0.shape} vs {I1.shape}")
         H, W = I0.shape
-        out = np.empty((H, W, 2), np.float32)
+        out = self._out((H, W, 2))
         st = _lib.TfStats()
         _lib.check(self._L.tf_calc_pair(self._h, I0.ctypes.data, I1.ctypes.data, H, W, out.ctypes.data, C.byref(st)),
                    self._h, "tf_calc_pair")
@@ -147,7 +196,7 @@ class DenseFlow:
         N, H, W = frames.shape
         if N < 2:
             raise OpticalFlowCalculationError("need at least 2 frames")
-        out = np.empty((N - 1, H, W, 2), np.float32)
+        out = self._out((N - 1, H, W, 2))
         st = _lib.TfStats()
         _lib.check(self._L.tf_calc_seq(self._h, frames.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(st)),
                    self._h, "tf_calc_seq")
@@ -170,7 +219,7 @@ class DenseFlow:
         if nparr.shape[3] != 3 or nparr.shape[0] < 2:
             raise OpticalFlowCalculationError(f"nparr must be [N>=2,H,W,3], got {nparr.shape}")
         N, H, W, _ = nparr.shape
-        out = np.empty((N - 1, H, W, 2), np.float32)
+        out = self._out((N - 1, H, W, 2))
         st = _lib.TfStats()
         _lib.check(self._L.tf_calc_seq_rgb(self._h, nparr.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(st)),
                    self._h, "tf_calc_seq_rgb")
@@ -199,7 +248,7 @@ class DenseFlow:
         if I0s.shape != I1s.shape:
             raise OpticalFlowCalculationError(f"I0s and I1s sizes differ: {I0s.shape} vs {I1s.shape}")
         B, H, W = I0s.shape
-        out = np.empty((B, H, W, 2), np.float32)
+        out = self._out((B, H, W, 2))
         st = _lib.TfStats()
         _lib.check(self._L.tf_calc_pairs(self._h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, out.ctypes.data, C.byref(st)),
                    self._h, "tf_calc_pairs")

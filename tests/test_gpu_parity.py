@@ -315,3 +315,31 @@ print(json.dumps({{"layout": d, "payload_ok": ok}}))
     fr = condition_frames(np.load(str(tmp_path / "nparr.npy")))
     assert np.array_equal(flow[0], oracle.tvl1_calc(fr[0], fr[1]) * (0.04 * 50.0))
     assert np.array_equal(flow[-1], flow[-2])
+
+
+def test_pinned_result_path_overlapped_copy_out_equals_pageable_path(oracle):
+    """Results returned by DenseFlow live in pooled pinned host memory (copy-out of a sub-batch overlaps the solve of the
+    next: 52 pairs through a capacity of 16); a pageable destination handed to the C ABI directly takes the in-order path.
+    Same bits, and buffers are recycled."""
+    import ctypes as C
+    import gc
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd import _lib
+    from tee_optical_flow_amd.synth import speckle_pairs
+    I0s, I1s = speckle_pairs(range(300, 352), 64, 96)
+    eng = T.DenseFlow(max_batch=16)
+    a = eng.calc_pairs(I0s, I1s)
+    it_a = eng.last_iters().copy()
+    out = np.empty((52, 64, 96, 2), np.float32)                  # pageable
+    st = _lib.TfStats()
+    _lib.check(eng._L.tf_calc_pairs(eng._h, I0s.ctypes.data, I1s.ctypes.data, 52, 64, 96, out.ctypes.data, C.byref(st)), eng._h)
+    assert np.array_equal(a, out) and np.array_equal(it_a, eng.last_iters())
+    for b in (0, 17, 51):
+        assert np.array_equal(a[b], oracle.tvl1_calc(I0s[b], I1s[b]))
+    addr = a.ctypes.data
+    keep = a[3].copy()
+    del a
+    gc.collect()
+    b2 = eng.calc_pairs(I0s, I1s)                                # the pooled buffer comes back
+    assert b2.ctypes.data == addr and np.array_equal(b2[3], keep)
+    eng.close()
