@@ -332,11 +332,53 @@ struct MedArgs {
     Geom g;
 };
 
+// median of a staged (TH+2R) x (TW+2R) tile: 5x5 -> each thread produces FOUR horizontally adjacent outputs from one 5x8
+// window (tf_median25_row4: shared column sorts and merges, 76 min/max/med3 per output instead of 198); 3x3 -> one
+// output per thread and row as before.
+template <int KS, int LW>
+__device__ __forceinline__ void median_tile(const float (*t)[LW], float* __restrict__ dst, int x0, int y0, int W, int H, int pitch)
+{
+    if constexpr (KS == 5) {
+        const int qx = threadIdx.x & 15, ly = threadIdx.x >> 4;        // 16 quads x 16 rows = the 64 x 16 tile
+        const int x = x0 + 4 * qx, y = y0 + ly;
+        if (x < W && y < H) {
+            float col[8][5], out[4];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const float4 lo = *reinterpret_cast<const float4*>(&t[ly + r][4 * qx]);
+                const float4 hi = *reinterpret_cast<const float4*>(&t[ly + r][4 * qx + 4]);
+                col[0][r] = lo.x; col[1][r] = lo.y; col[2][r] = lo.z; col[3][r] = lo.w;
+                col[4][r] = hi.x; col[5][r] = hi.y; col[6][r] = hi.z; col[7][r] = hi.w;
+            }
+            tf_median25_row4(col, out);
+            float* o = dst + (size_t)y * pitch + x;
+            if (x + 3 < W) *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);
+            else
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (x + i < W) o[i] = out[i];
+        }
+    } else {
+        const int lx = threadIdx.x & 63, x = x0 + lx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ly = (threadIdx.x >> 6) + 4 * r, y = y0 + ly;
+            if (x < W && y < H) {
+                float p[KS * KS];
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+#pragma unroll
+                    for (int i = 0; i < KS; ++i) p[j * KS + i] = t[ly + j][lx + i];
+                dst[(size_t)y * pitch + x] = tf_median9(p);
+            }
+        }
+    }
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void k_median(MedArgs a)
 {
     constexpr int R = KS / 2, TWm = 64, THm = 16, LW = TWm + 2 * R, LH = THm + 2 * R;
-    __shared__ float t[LH][LW];
+    __shared__ __attribute__((aligned(16))) float t[LH][LW];
     const int b = blockIdx.z >> 1, plane = blockIdx.z & 1;
     if (!pair_active(a.err + (size_t)b * a.errstride, a.it, a.thr_q)) return;
     const int uc = (a.ctl[b].ubase ^ a.utog) & 1;
@@ -349,19 +391,7 @@ __global__ __launch_bounds__(256) void k_median(MedArgs a)
         for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, x = x0 + lx;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ly = (threadIdx.x >> 6) + 4 * r, y = y0 + ly;
-        if (x < W && y < H) {
-            float p[KS * KS];
-#pragma unroll
-            for (int j = 0; j < KS; ++j)
-#pragma unroll
-                for (int i = 0; i < KS; ++i) p[j * KS + i] = t[ly + j][lx + i];
-            dst[(size_t)y * pitch + x] = (KS == 5) ? tf_median25(p) : tf_median9(p);
-        }
-    }
+    median_tile<KS, LW>(t, dst, x0, y0, W, H, pitch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1226,7 +1256,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
 {
     constexpr int R = KS / 2, TWm = 64, THm = 16, LW = TWm + 2 * R, LH = THm + 2 * R;
-    __shared__ float t[LH][LW];
+    __shared__ __attribute__((aligned(16))) float t[LH][LW];
     const int b = blockIdx.z >> 1, plane = blockIdx.z & 1;
     if (pair_mode2(a.err + (size_t)b * a.errstride, a.it, total, a.thr_q) != M_NORMAL) return;
     const int uc = (a.ctl[b].ubase ^ a.utog) & 1;
@@ -1239,19 +1269,7 @@ __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
         for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, x = x0 + lx;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ly = (threadIdx.x >> 6) + 4 * r, y = y0 + ly;
-        if (x < W && y < H) {
-            float p[KS * KS];
-#pragma unroll
-            for (int j = 0; j < KS; ++j)
-#pragma unroll
-                for (int i = 0; i < KS; ++i) p[j * KS + i] = t[ly + j][lx + i];
-            dst[(size_t)y * pitch + x] = (KS == 5) ? tf_median25(p) : tf_median9(p);
-        }
-    }
+    median_tile<KS, LW>(t, dst, x0, y0, W, H, pitch);
 }
 
 // stage end for the two-iterations-per-launch schedule: a pair took part in ceil(n_it/2) launches
