@@ -242,7 +242,6 @@ def main():
         tp = time.perf_counter()
         eng.calc_pairs(I0s, I1s)
         out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
-        del fh
         if world == 1 and not a.no_cpu_baseline:
             n = min(a.cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n, a.algo)

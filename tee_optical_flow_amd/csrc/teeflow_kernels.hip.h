@@ -161,12 +161,18 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs a)
     float vI = 0.f, vX = 0.f, vY = 0.f;
     if (!(ix >= W || ix + 4 <= 0 || iy >= H || iy + 4 <= 0)) {
         float P[6][6];
+        unsigned xo[6], yo[6];                             // unsigned 32-bit BYTE offsets from the frame base (a plane is < 2^24 px):
+                                                           // the loads take the scalar-base + 32-bit-offset form, no 64-bit address math
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const float* row = I1 + (size_t)clampi(iy - 1 + j, 0, H - 1) * pitch;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) P[j][i] = row[clampi(ix - 1 + i, 0, W - 1)];
+        for (int i = 0; i < 6; ++i) {
+            xo[i] = (unsigned)clampi(ix - 1 + i, 0, W - 1) * 4u;
+            yo[i] = (unsigned)clampi(iy - 1 + i, 0, H - 1) * (unsigned)pitch * 4u;
         }
+        const char* base1 = reinterpret_cast<const char*>(I1);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) P[j][i] = *reinterpret_cast<const float*>(base1 + (yo[j] + xo[i]));
         float wgt[16];
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1)
