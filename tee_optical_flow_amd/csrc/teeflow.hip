@@ -90,8 +90,9 @@ struct tf_handle {
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
-                                 // while one lane runs the thin tail of a stage, the other fills the GPU (+6 % measured; 4 lanes lose)
-    tf_handle* twin = nullptr; bool is_twin = false;
+                                 // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
+                                 // @512^2: 1 lane 2180, 2 lanes 2470, 3 lanes 2415, 4 lanes 2165 pairs/s (DeepFlow 377 vs 309)
+    std::vector<tf_handle*> twins; bool is_twin = false;   // extra lanes (own stream, buffers, host thread each)
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
@@ -816,47 +817,62 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     return TF_OK;
 }
 
-// Entry used by the C ABI: optionally splits the batch over two lanes (this handle + a twin with its own stream / buffers)
+// Entry used by the C ABI: optionally splits the batch over several lanes (this handle + twins with their own stream,
+// buffers and host thread): the launch gaps and thin tail launches of one lane are filled by the others.
 int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
                float* flow_out, bool device, tf_stats* st)
 {
     if (!h) return TF_ERR_INVALID_ARG;
-    if (h->lanes < 2 || h->is_twin || n_pairs < 32 || !in0 || !flow_out || (mode == MODE_PAIRS && !in1) || H < 1 || W < 1 || h->stream != h->own_stream)
+    int L = h->lanes;
+    while (L > 1 && n_pairs / L < 16) --L;                   // a lane needs a batch worth its launches
+    if (L < 2 || h->is_twin || !in0 || !flow_out || (mode == MODE_PAIRS && !in1) || H < 1 || W < 1 || h->stream != h->own_stream)
         return calc_common(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
-    if (!h->twin) {
-        int rc = h->P.algo == TF_ALGO_DEEPFLOW ? tf_create_deepflow(&h->DP, h->dev, &h->twin) : tf_create(&h->P, h->dev, &h->twin);
-        if (rc) return fail(h, rc, "creating the second lane failed: %s", tf_last_error(nullptr));
-        h->twin->is_twin = true;
+    while ((int)h->twins.size() < L - 1) {
+        tf_handle* t = nullptr;
+        int rc = h->P.algo == TF_ALGO_DEEPFLOW ? tf_create_deepflow(&h->DP, h->dev, &t) : tf_create(&h->P, h->dev, &t);
+        if (rc) return fail(h, rc, "creating lane %d failed: %s", (int)h->twins.size() + 2, tf_last_error(nullptr));
+        t->is_twin = true;
+        h->twins.push_back(t);
     }
-    tf_handle* t = h->twin;
-    t->P = h->P; t->DP = h->DP; t->profile = h->profile;
-    t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
-    t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
-    t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-    t->sub_batches = h->sub_batches;
     const size_t fpx = (size_t)H * W;
-    const int nA = n_pairs / 2, nB = n_pairs - nA;
-    const uint8_t* b0 = mode == MODE_SEQ ? in0 + (size_t)nA * fpx : in0 + (size_t)nA * fpx;      // SEQ: frames nA..n_pairs (1-frame overlap)
-    const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)nA * fpx;
-    tf_stats sa, sb;
-    int rcB = TF_OK;
-    std::thread lane([&] { rcB = calc_common(t, mode, b0, b1, nB, H, W, scale, flow_out + (size_t)nA * fpx * 2, device, &sb); });
-    const int rcA = calc_common(h, mode, in0, in1, nA, H, W, scale, flow_out, device, &sa);
-    lane.join();
-    if (rcA) return rcA;
-    if (rcB) return fail(h, rcB, "%s", t->err.c_str());
-    h->last_iters.insert(h->last_iters.end(), t->last_iters.begin(), t->last_iters.end());
+    std::vector<tf_stats> ss((size_t)L);
+    std::vector<int> rcs((size_t)L, TF_OK), first((size_t)L + 1, 0);
+    for (int k = 0; k <= L; ++k) first[k] = (int)((long long)n_pairs * k / L);
+    std::vector<std::thread> th;
+    for (int k = 1; k < L; ++k) {
+        tf_handle* t = h->twins[k - 1];
+        t->P = h->P; t->DP = h->DP; t->profile = h->profile;
+        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
+        t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
+        t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
+        t->sub_batches = h->sub_batches;
+        // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
+        const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
+        const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
+        const int nb = first[k + 1] - first[k];
+        float* fo = flow_out + (size_t)first[k] * fpx * 2;
+        th.emplace_back([=, &ss, &rcs] { rcs[k] = calc_common(t, mode, b0, b1, nb, H, W, scale, fo, device, &ss[k]); });
+    }
+    rcs[0] = calc_common(h, mode, in0, in1, first[1], H, W, scale, flow_out, device, &ss[0]);
+    for (auto& x : th) x.join();
+    if (rcs[0]) return rcs[0];
+    for (int k = 1; k < L; ++k)
+        if (rcs[k]) return fail(h, rcs[k], "%s", h->twins[k - 1]->err.c_str());
+    for (int k = 1; k < L; ++k) h->last_iters.insert(h->last_iters.end(), h->twins[k - 1]->last_iters.begin(), h->twins[k - 1]->last_iters.end());
     h->last_pairs = n_pairs;
     if (st) {
-        *st = sa;
+        *st = ss[0];
         st->n_pairs = n_pairs;
-        st->ms_total = sa.ms_total > sb.ms_total ? sa.ms_total : sb.ms_total;
-        st->ms_h2d = sa.ms_h2d > sb.ms_h2d ? sa.ms_h2d : sb.ms_h2d;
-        st->ms_device = sa.ms_device > sb.ms_device ? sa.ms_device : sb.ms_device;
-        st->ms_d2h = sa.ms_d2h > sb.ms_d2h ? sa.ms_d2h : sb.ms_d2h;
-        st->iter_launches += sb.iter_launches; st->iter_pair_steps += sb.iter_pair_steps; st->iter_ms += sb.iter_ms;
-        st->iter_bytes += sb.iter_bytes; st->total_bytes += sb.total_bytes;
-        st->inner_iters_total += sb.inner_iters_total; st->outer_iters_total += sb.outer_iters_total;
+        for (int k = 1; k < L; ++k) {
+            const tf_stats& sb = ss[k];
+            st->ms_total = std::max(st->ms_total, sb.ms_total);
+            st->ms_h2d = std::max(st->ms_h2d, sb.ms_h2d);
+            st->ms_device = std::max(st->ms_device, sb.ms_device);
+            st->ms_d2h = std::max(st->ms_d2h, sb.ms_d2h);
+            st->iter_launches += sb.iter_launches; st->iter_pair_steps += sb.iter_pair_steps; st->iter_ms += sb.iter_ms;
+            st->iter_bytes += sb.iter_bytes; st->total_bytes += sb.total_bytes;
+            st->inner_iters_total += sb.inner_iters_total; st->outer_iters_total += sb.outer_iters_total;
+        }
     }
     return TF_OK;
 }
@@ -990,7 +1006,8 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
 TF_API void tf_destroy(tf_handle* h)
 {
     if (!h) return;
-    if (h->twin) { tf_destroy(h->twin); h->twin = nullptr; }
+    for (tf_handle* t : h->twins) tf_destroy(t);
+    h->twins.clear();
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_buffers(h);
@@ -1078,7 +1095,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
-    else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 2 ? 2 : value);
+    else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
