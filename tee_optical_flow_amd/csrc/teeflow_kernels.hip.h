@@ -953,7 +953,7 @@ __device__ __forceinline__ int pair_mode2(const u64* e, int it, int total, doubl
 // Work items of a tvl1_iter launch when the strips are sized ON THE DEVICE from the number of pairs that still
 // iterate (`n`): one round of at most `slots` resident blocks (slots = CUs x blocks per CU), each marching a strip that is
 // as long as that allows -- a lock-step batch loses a third of its time otherwise (a launch with 1024 blocks on 768 slots
-// takes two rounds, one with 300 takes as long as one with 768).  Returns rows per strip (a multiple of RY) and the strip count.
+// takes two rounds, one with 300 takes as long as one with 768).  Returns rows per strip and the strip count.
 TF_HD inline void strip_rule(int n, int H, int RY, int slots, int* R, int* S)
 {
     if (n < 1) n = 1;
@@ -963,7 +963,6 @@ TF_HD inline void strip_rule(int n, int H, int RY, int slots, int* R, int* S)
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     int r = (H + s - 1) / s;
-    r = (r + RY - 1) / RY * RY;
     *R = r;
     *S = (H + r - 1) / r;
 }
@@ -1047,8 +1046,8 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
     const int x = tx * 4;
     const int y0 = strip * R;
-    const int n = R / RY;
-    const int ngroups = n + 2 + (RY == 1 ? 1 : 0);
+    // the first primal update covers rows y0-1 .. y0+R+1; groups of RY rows start at y0-1 (R need not be a multiple of RY)
+    const int ngroups = (R + 3 + RY - 1) / RY;
     const size_t po = (size_t)b * a.g.splane;
     const int RB = RY + 1;
 
@@ -1092,7 +1091,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     for (int s = 0; s < ngroups + 2; ++s) {
         // ================= stage 1: group s, iteration `it` primal =================
         const int r1 = s * RY + ty;                       // linear row counter inside the strip's pipeline
-        const int y = y0 - RY + r1;
+        const int y = y0 - 1 + r1;
         const bool v1 = lane_on && s < ngroups && y >= 0 && y < H && y >= yu1_lo && y <= yu1_hi;
         const size_t row = (size_t)y * pitch + x;
         float4 u1q, u2q, wxq, wyq, rq, a11, a12, a21, a22;

@@ -105,8 +105,8 @@ def test_input_validation_happens_before_any_gpu_work():
 
 
 def test_strip_rule_covers_the_image_and_fills_one_round():
-    """Host arithmetic behind the device-side strip sizing of tvl1_iter: strips cover every row, are a multiple of the
-    rows-per-step, and the work items of a launch fit the resident-block budget in whole rounds."""
+    """Host arithmetic behind the device-side strip sizing of tvl1_iter: strips cover every row and the work items of a
+    launch fit the resident-block budget in whole rounds."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
     R, S = C.c_int(), C.c_int()
@@ -115,11 +115,11 @@ def test_strip_rule_covers_the_image_and_fills_one_round():
             for n in list(range(1, 130)) + [255, 768, 769, 1024]:
                 L.tf_dbg_strip_rule(n, H, RY, slots, C.byref(R), C.byref(S))
                 r, s = R.value, S.value
-                assert r >= RY and r % RY == 0 and s >= 1
+                assert r >= 1 and s >= 1
                 assert (s - 1) * r < H <= s * r, (H, RY, slots, n, r, s)          # strips tile the rows, none is empty
                 rounds = -(-n // slots)
                 assert n * s <= rounds * slots or s == 1, (H, RY, slots, n, r, s)  # never more items than the rounds hold
     L.tf_dbg_strip_rule(64, 512, 2, 768, C.byref(R), C.byref(S))
-    assert (R.value, S.value) == (44, 12)
+    assert (R.value, S.value) == (43, 12)
     L.tf_dbg_strip_rule(1, 512, 2, 768, C.byref(R), C.byref(S))
     assert R.value == 8 and S.value == 64                                       # capped: at least 4 steps per strip
