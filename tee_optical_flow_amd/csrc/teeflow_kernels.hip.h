@@ -1143,6 +1143,10 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
             const unsigned mnl = opaque_u(lastrow ? 0u : ~0u);
             float dv1[4], dv2[4], u1x[4], u1y[4], u2x[4], u2y[4];
             UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
+            {   // the thread's own quad of the first iterate lives in LDS since stage 1 of the previous step
+                const float4 o1 = ld4(U1a + (bp * RY + ty) * LW + x), o2 = ld4(U1b + (bp * RY + ty) * LW + x);
+                UNPACK4(s1_u1, o1) UNPACK4(s1_u2, o2)
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float e1 = i < 3 ? s1_u1[i + 1] : rr1, e2 = i < 3 ? s1_u2[i + 1] : rr2;
@@ -1212,6 +1216,10 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
                 const unsigned mnl = opaque_u(lastrow ? 0u : ~0u);
                 float dv1[4], dv2[4], r11[4], r12[4], r21[4], r22[4], u1x[4], u1y[4], u2x[4], u2y[4];
                 UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
+                {   // own quad of the second iterate: in LDS since stage 2 of the previous step
+                    const float4 o1 = ld4(U2a + (bq * RY + ty) * LW + x), o2 = ld4(U2b + (bq * RY + ty) * LW + x);
+                    UNPACK4(s2_u1, o1) UNPACK4(s2_u2, o2)
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float e1 = i < 3 ? s2_u1[i + 1] : rr1, e2 = i < 3 ? s2_u2[i + 1] : rr2;
@@ -1231,9 +1239,8 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         s2_valid = v2u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            s2_u1[i] = m_u1[i]; s2_u2[i] = m_u2[i];
             s2_11[i] = p1_11[i]; s2_12[i] = p1_12[i]; s2_21[i] = p1_21[i]; s2_22[i] = p1_22[i];
-            s1_u1[i] = n_u1[i]; s1_u2[i] = n_u2[i]; s1_wx[i] = wxv[i]; s1_wy[i] = wyv[i]; s1_r[i] = rv[i];
+            s1_wx[i] = wxv[i]; s1_wy[i] = wyv[i]; s1_r[i] = rv[i];
             s1_11[i] = c11[i]; s1_12[i] = c12[i]; s1_21[i] = c21[i]; s1_22[i] = c22[i];
         }
         s1_valid = v1;
