@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity for the DeepFlow path: random sizes and batch sizes, flows compared bit for bit.
+usage: python tools/fuzz_deepflow.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import tee_optical_flow_amd as T
+    from oracle import oracle as O
+    from tee_optical_flow_amd.synth import speckle_pairs
+    rng = np.random.default_rng(seed)
+    bad = 0
+    t0 = time.time()
+    for c in range(cases):
+        H = int(rng.integers(26, 150)); W = int(rng.integers(26, 180)); B = int(rng.choice([1, 2, 5, 33]))
+        I0s, I1s = speckle_pairs(range(500 * c, 500 * c + B), H, W)
+        if rng.random() < 0.25:
+            I1s[0] = I0s[0]
+        eng = T.DenseFlow(algo="deepflow", max_batch=int(rng.choice([B, max(1, B // 2)])))
+        eng.set_tuning("sor_fuse", int(rng.choice([0, 1, 2, 3, 5])))
+        flows = eng.calc_pairs(I0s, I1s)
+        ok = True
+        for b in sorted(set([0, B - 1])):
+            ref = O.deepflow_calc(I0s[b], I1s[b])
+            if not np.array_equal(flows[b], ref):
+                ok = False
+                print(f"MISMATCH case {c} pair {b}: {H}x{W} B={B}: {np.sum(flows[b] != ref)} values differ, max {np.abs(flows[b] - ref).max()}", flush=True)
+        bad += not ok
+        eng.close()
+        print(f"case {c}: {H}x{W} B={B} {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"{cases - bad}/{cases} cases identical in {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
