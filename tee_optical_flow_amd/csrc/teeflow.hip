@@ -87,7 +87,7 @@ struct tf_handle {
     double* an_rad = nullptr; double* an_lon = nullptr; int anN = 0, anH = 0, anW = 0;
     // tuning knobs (tf_set_tuning)
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
-                                 // iterations per launch (k_iter2_rows); 1 and 2 need W <= 1024 and enough rows*pairs
+                                 // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
@@ -96,6 +96,8 @@ struct tf_handle {
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
+    int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
+                                 // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
     int sub_batches = 1;         // >1 cuts a host-pointer call that fits the capacity into that many sub-batches so the copy-out of
                                  // one overlaps the solve of the next; measured at 128 pairs @512^2: smaller batches cost more (2099 /
                                  // 2030 / 1886 / 1701 pairs/s for 1 / 2 / 3 / 4) than the 5 ms of D2H they hide.  Calls larger than
@@ -250,10 +252,10 @@ struct StageTotals {
     double iter_bytes = 0, total_bytes = 0;
 };
 
-// full-width strips need W <= 1024 and enough rows*pairs to fill 256 CUs; tiny launches (single-pair latency mode) keep the tiles
+// full-width strips need W <= max_strip_width (at most 2048: one quad per thread, 512 threads) and enough rows*pairs to fill 256 CUs; tiny launches (single-pair latency mode) keep the tiles
 bool rows_ok(const tf_handle* h, const Geom& g, int B)
 {
-    return h->iter_variant >= 1 && g.w <= 1024 && (long long)g.h * B >= h->min_rows_work;
+    return h->iter_variant >= 1 && g.w <= h->max_strip_width && (long long)g.h * B >= h->min_rows_work;
 }
 
 // Block shape of the row-strip kernels: QX quads per row, RY = floor(256/QX) rows per step, 256 threads.
@@ -845,7 +847,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1094,6 +1096,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
+    else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_iter(IterArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// tvl1_iter, row-strip form (the one the solver launches for W <= 1024): same arithmetic as k_iter,
+// tvl1_iter, row-strip form (single-iteration variant; W <= 2048): same arithmetic as k_iter,
 // different traffic shape.  A block owns R full-width rows of one pair and marches down them RY rows
 // per step (thread = one float4 quad of one row).  Full-width rows mean every 128-B line of every plane
 // is fetched exactly once per launch (no x halo; the 64x16 tiles of k_iter start at 240-B offsets and

@@ -150,13 +150,16 @@ def test_two_lane_split_of_large_batches(oracle):
     eng.close()
 
 
-def test_wide_image_uses_tile_kernel_and_matches(oracle):
-    """W > 1024 cannot use the full-width strip kernels: the 64x16-tile form takes over (same bits)."""
+@pytest.mark.parametrize("width,max_strip_width", [(1100, 2048), (1100, 1024), (2050, 2048)])
+def test_wide_images_strip_kernel_up_to_2048_then_tiles(oracle, width, max_strip_width):
+    """Levels up to 2048 px wide run the full-width strip kernel (512-thread blocks above 1024 px); wider ones, or a lower
+    `max_strip_width`, the 64x16-tile form.  Same bits either way."""
     import tee_optical_flow_amd as T
     from tee_optical_flow_amd.synth import speckle_pair
-    I0, I1, _ = speckle_pair(90, 48, 1100)
+    I0, I1, _ = speckle_pair(90, 48, width)
     eng = T.DenseFlow(nscales=3)
     eng.set_tuning("min_rows_work", 0)
+    eng.set_tuning("max_strip_width", max_strip_width)
     out = eng.calc(I0, I1, None)
     ref, ref_it, nl = oracle.tvl1_calc(I0, I1, oracle.default_params(nscales=3), return_iters=True)
     assert np.array_equal(eng.last_iters()[0], ref_it[:nl]) and np.array_equal(out, ref)
