@@ -96,6 +96,7 @@ struct tf_handle {
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
+    int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
     int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
                                  // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
     int sub_batches = 1;         // >1 cuts a host-pointer call that fits the capacity into that many sub-batches so the copy-out of
@@ -280,6 +281,10 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
 void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int active_hint = 0)
 {
     const Geom& g = A.a.g;
+    if (!rows_ok(h, g, B)) {      // small launches and very wide levels: tiles
+        hipLaunchKernelGGL(k_iter2_tile, dim3((g.w + T2_OW - 1) / T2_OW, (g.h + T2_OH - 1) / T2_OH, B), dim3(256), 0, s, A);
+        return;
+    }
     int R, QX, RY, threads;
     // rows per strip follow the number of pairs known to be still iterating: the thin tail launches of a stage get many
     // short strips (latency of a few steps) instead of a few long ones
@@ -369,7 +374,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
-    const bool two = h->iter_variant == 2 && rows_ok(h, g, B) && (inner % 2 == 0);
+    const bool two = h->iter_variant == 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0);
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
         int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
@@ -847,7 +852,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1096,6 +1101,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
+    else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
@@ -1611,7 +1617,7 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     }
     ia.ctl = ctl; ia.err = errs; ia.errstride = nsteps + 1; ia.thr_q = -1.0; ia.g = g; ia.host_slot = nullptr; ia.B = 1;
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
-    const bool two = h->iter_variant == 2 && rows_ok(h, g, 1) && nsteps % 2 == 0;
+    const bool two = h->iter_variant == 2 && (rows_ok(h, g, 1) || h->tile2) && nsteps % 2 == 0;
     int launches = 0;
     if (two) {
         for (int it = 0; it < nsteps; it += 2, ++launches) {

@@ -1263,6 +1263,156 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tvl1_iter, two iterations per launch on TILES: the form for launches too small for the row strips (a single pair, a
+// handful of pairs) and for levels wider than 2048 px.  Same schedule, modes (NORMAL / REPLAY / EXIT) and arithmetic as
+// k_iter2_rows; a block stages a 64 x 16 region (16 quads x 16 rows, region origin 4 px left of and 1 row above its
+// outputs) and produces the 52 x 13 outputs whose dependency cone (1 px left / 1 row up for the primal updates, 1 px
+// right / 1 row down for the dual updates, twice) stays inside the region:
+//     U1 on quads 0..15, rows 0..15 | P1 on quads 0..14, rows 0..14 | U2 on quads 1..14, rows 1..14 | P2, store: quads 1..13, rows 1..13
+// Halving the number of dependent launches is what matters here: a single 512 x 512 pair spends its 4 ms in ~390 launches.
+// ---------------------------------------------------------------------------------------------
+#define T2_OW 52
+#define T2_OH 13
+
+__global__ __launch_bounds__(256) void k_iter2_tile(Iter2Args A)
+{
+    constexpr int LW = 68;
+    __shared__ __attribute__((aligned(16))) float sA[16][LW], sB[16][LW];      // u1 / u2 of the first, then of the second iterate
+    __shared__ __attribute__((aligned(16))) float s12[16][LW], s22[16][LW];    // p1_12 / p1_22
+    __shared__ float s11w[16][16], s21w[16][16];                               // last element of each quad of p1_11 / p1_21
+    __shared__ u64 sred[8];
+    const IterArgs& a = A.a;
+    publish_active_count2(A);
+    const int b = blockIdx.z;
+    u64* errb = a.err + (size_t)b * a.errstride;
+    const int mode = pair_mode2(errb, a.it, A.total, a.thr_q);                  // block-uniform
+    if (mode == M_EXIT) return;
+    const bool replay = mode == M_REPLAY;
+    const PairCtl c = a.ctl[b];
+    const int utog = replay ? A.utog_prev : a.utog, ptog = replay ? A.ptog_prev : a.ptog;
+    const bool pzero = (replay ? A.pzero_prev : a.pzero) != 0;
+    const int uc = (c.ubase ^ utog) & 1, pc = (c.pbase ^ ptog) & 1;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    const int x = (int)blockIdx.x * T2_OW - 4 + tx * 4, y = (int)blockIdx.y * T2_OH - 1 + ty;
+    const bool inr = x >= 0 && x < W && y >= 0 && y < H;
+    const bool outq = inr && tx >= 1 && tx <= 13 && ty >= 1 && ty <= 13;        // this thread's quad is an output of the block
+    const size_t po = (size_t)b * a.g.splane;
+    const size_t row = po + (size_t)(inr ? y : 0) * pitch + (inr ? x : 0);
+
+    unsigned inw[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) inw[j] = opaque_u(x + j < W ? ~0u : 0u);
+    const unsigned mnl = opaque_u(y >= H - 1 ? 0u : ~0u);
+    const unsigned mout = opaque_u(outq ? ~0u : 0u);
+    const unsigned keep[4] = {inw[0] & mout, inw[1] & mout, inw[2] & mout, inw[3] & mout};
+
+    float u0_1[4], u0_2[4], wx[4], wy[4], rc[4], p0_11[4], p0_12[4], p0_21[4], p0_22[4];
+    float u1_1[4], u1_2[4];
+    double accA = 0.0, accB = 0.0;
+    // ---- first primal update on the whole region ----
+    if (inr) {
+        const float4 u1q = ld4(a.sb.u1[uc] + row), u2q = ld4(a.sb.u2[uc] + row);
+        const float4 wxq = ld4(a.wx + row), wyq = ld4(a.wy + row), rq = ld4(a.rho + row);
+        float4 a11 = make_float4(0, 0, 0, 0), a12 = a11, a21 = a11, a22 = a11, up12 = a11, up22 = a11;
+        float l11 = 0.f, l21 = 0.f;
+        if (!pzero) {
+            a11 = ld4(a.sb.p11[pc] + row); a12 = ld4(a.sb.p12[pc] + row);
+            a21 = ld4(a.sb.p21[pc] + row); a22 = ld4(a.sb.p22[pc] + row);
+            if (y > 0) { up12 = ld4(a.sb.p12[pc] + row - pitch); up22 = ld4(a.sb.p22[pc] + row - pitch); }
+            if (x > 0) { l11 = a.sb.p11[pc][row - 1]; l21 = a.sb.p21[pc][row - 1]; }
+        }
+        QuadU qu;
+        UNPACK4(qu.u1k, u1q) UNPACK4(qu.u2k, u2q) UNPACK4(qu.wx, wxq) UNPACK4(qu.wy, wyq) UNPACK4(qu.r, rq)
+        UNPACK4(qu.p11, a11) UNPACK4(qu.p12, a12) UNPACK4(qu.p21, a21) UNPACK4(qu.p22, a22)
+        UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
+        qu.l11 = l11; qu.l21 = l21;
+        UNPACK4(u0_1, u1q) UNPACK4(u0_2, u2q) UNPACK4(wx, wxq) UNPACK4(wy, wyq) UNPACK4(rc, rq)
+        UNPACK4(p0_11, a11) UNPACK4(p0_12, a12) UNPACK4(p0_21, a21) UNPACK4(p0_22, a22)
+        tv_u_quad_pk(a.l_t, a.theta, qu, y == 0, x == 0, u1_1, u1_2);
+        if (!replay) accA += tv_err_quad_pk(u1_1, u0_1, u1_2, u0_2, keep);
+        st4(&sA[ty][tx * 4], PACK4(u1_1));
+        st4(&sB[ty][tx * 4], PACK4(u1_2));
+    }
+    __syncthreads();
+    // ---- first dual update: quads 0..14, rows 0..14 (the right / lower neighbour of the first iterate is in the region) ----
+    float p1_11[4], p1_12[4], p1_21[4], p1_22[4];
+    const bool vP1 = inr && tx <= 14 && ty <= 14;
+    if (vP1) {
+        const float4 dn1 = ld4(&sA[ty + 1][tx * 4]), dn2 = ld4(&sB[ty + 1][tx * 4]);     // masked where y is the last image row
+        const float rr1 = sA[ty][tx * 4 + 4], rr2 = sB[ty][tx * 4 + 4];                 // masked where the column is the last one
+        float dv1[4], dv2[4], u1x[4], u1y[4], u2x[4], u2y[4];
+        UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e1 = i < 3 ? u1_1[i + 1] : rr1, e2 = i < 3 ? u1_2[i + 1] : rr2;
+            u1x[i] = mask_f(e1 - u1_1[i], inw[i + 1]); u2x[i] = mask_f(e2 - u1_2[i], inw[i + 1]);
+            u1y[i] = mask_f(dv1[i] - u1_1[i], mnl); u2y[i] = mask_f(dv2[i] - u1_2[i], mnl);
+        }
+        tv_p_quad_pk(a.taut, u1x, u1y, u2x, u2y, p0_11, p0_12, p0_21, p0_22, p1_11, p1_12, p1_21, p1_22);
+        if (replay) {
+            if (outq) {
+                st4(a.sb.u1[uc ^ 1] + row, PACK4(u1_1)); st4(a.sb.u2[uc ^ 1] + row, PACK4(u1_2));
+                st4(a.sb.p11[pc ^ 1] + row, PACK4(p1_11)); st4(a.sb.p12[pc ^ 1] + row, PACK4(p1_12));
+                st4(a.sb.p21[pc ^ 1] + row, PACK4(p1_21)); st4(a.sb.p22[pc ^ 1] + row, PACK4(p1_22));
+            }
+        } else {
+            st4(&s12[ty][tx * 4], PACK4(p1_12));
+            st4(&s22[ty][tx * 4], PACK4(p1_22));
+            s11w[ty][tx] = p1_11[3];
+            s21w[ty][tx] = p1_21[3];
+        }
+    }
+    if (replay) return;                                                          // block-uniform
+    __syncthreads();
+    // ---- second primal update: quads 1..14, rows 1..14 ----
+    float u2_1[4], u2_2[4];
+    const bool vU2 = vP1 && tx >= 1 && ty >= 1;
+    if (vU2) {
+        const float4 up12 = ld4(&s12[ty - 1][tx * 4]), up22 = ld4(&s22[ty - 1][tx * 4]);  // unused in the first image row
+        QuadU qu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qu.u1k[i] = u1_1[i]; qu.u2k[i] = u1_2[i]; qu.wx[i] = wx[i]; qu.wy[i] = wy[i]; qu.r[i] = rc[i];
+            qu.p11[i] = p1_11[i]; qu.p12[i] = p1_12[i]; qu.p21[i] = p1_21[i]; qu.p22[i] = p1_22[i];
+        }
+        UNPACK4(qu.p12u, up12) UNPACK4(qu.p22u, up22)
+        qu.l11 = s11w[ty][tx - 1]; qu.l21 = s21w[ty][tx - 1];                   // unused for the first image column
+        tv_u_quad_pk(a.l_t, a.theta, qu, y == 0, x == 0, u2_1, u2_2);
+        accB += tv_err_quad_pk(u2_1, u1_1, u2_2, u1_2, keep);
+        st4(&sA[ty][tx * 4], PACK4(u2_1));                                      // the first iterate's LDS copy was last read before the barrier above
+        st4(&sB[ty][tx * 4], PACK4(u2_2));
+    }
+    __syncthreads();
+    // ---- second dual update and store: quads 1..13, rows 1..13 ----
+    if (outq) {
+        const float4 dn1 = ld4(&sA[ty + 1][tx * 4]), dn2 = ld4(&sB[ty + 1][tx * 4]);
+        const float rr1 = sA[ty][tx * 4 + 4], rr2 = sB[ty][tx * 4 + 4];
+        float dv1[4], dv2[4], u1x[4], u1y[4], u2x[4], u2y[4], o11[4], o12[4], o21[4], o22[4];
+        UNPACK4(dv1, dn1) UNPACK4(dv2, dn2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e1 = i < 3 ? u2_1[i + 1] : rr1, e2 = i < 3 ? u2_2[i + 1] : rr2;
+            u1x[i] = mask_f(e1 - u2_1[i], inw[i + 1]); u2x[i] = mask_f(e2 - u2_2[i], inw[i + 1]);
+            u1y[i] = mask_f(dv1[i] - u2_1[i], mnl); u2y[i] = mask_f(dv2[i] - u2_2[i], mnl);
+        }
+        tv_p_quad_pk(a.taut, u1x, u1y, u2x, u2y, p1_11, p1_12, p1_21, p1_22, o11, o12, o21, o22);
+        st4(a.sb.u1[uc ^ 1] + row, PACK4(u2_1)); st4(a.sb.u2[uc ^ 1] + row, PACK4(u2_2));
+        st4(a.sb.p11[pc ^ 1] + row, PACK4(o11)); st4(a.sb.p12[pc ^ 1] + row, PACK4(o12));
+        st4(a.sb.p21[pc ^ 1] + row, PACK4(o21)); st4(a.sb.p22[pc ^ 1] + row, PACK4(o22));
+    }
+    u64 qA = (u64)accA, qB = (u64)accB;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { qA += __shfl_down(qA, off, 64); qB += __shfl_down(qB, off, 64); }
+    if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = qA; sred[4 + (threadIdx.x >> 6)] = qB; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&errb[a.it], sred[0] + sred[1] + sred[2] + sred[3]);
+        atomicAdd(&errb[a.it + 1], sred[4] + sred[5] + sred[6] + sred[7]);
+    }
+}
+
 // median for the two-iterations-per-launch schedule: a pair takes part iff it is in NORMAL mode at `it`
 template <int KS>
 __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
