@@ -112,7 +112,8 @@ struct tf_handle {
     int sor_fuse = 3;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 3 measured best
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
-    int min_rows_work = 4096;    // rows*pairs below which the tile kernel is used (tiny launches / single-pair latency)
+    int min_rows_work = 8192;    // rows*pairs of a level below which the tile kernels are used (measured at 512^2 with k_iter2_tile: 16 pairs
+                                 // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
 };

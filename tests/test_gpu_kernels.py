@@ -102,7 +102,7 @@ def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
         _iterate_case(engine, oracle, L, shape, pzero)
     finally:
         engine.set_tuning("iter_variant", 2)
-        engine.set_tuning("min_rows_work", 4096)
+        engine.set_tuning("min_rows_work", 8192)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
@@ -140,7 +140,7 @@ def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant
                                     _ptr(err)), engine._h)
     finally:
         engine.set_tuning("iter_variant", 2)
-        engine.set_tuning("min_rows_work", 4096)
+        engine.set_tuning("min_rows_work", 8192)
     for n, a, r in zip(["u1", "u2", "p11", "p12", "p21", "p22"], st, ref[:6]):
         bad = a.view(np.uint32) != r.view(np.uint32)
         assert not bad.any(), f"{n}: {bad.sum()} bit patterns differ, first at {np.argwhere(bad)[0]}: {a[bad][0]!r} vs {r[bad][0]!r}"
