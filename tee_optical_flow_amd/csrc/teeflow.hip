@@ -96,6 +96,7 @@ struct tf_handle {
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
+    int sor_whole = 1;           // DeepFlow: levels up to 96 x 96 run a whole fixed-point iteration's SOR in one launch
     int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
     int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
                                  // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
@@ -615,7 +616,20 @@ template <int S>
 void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s)
 {
     constexpr int RW = 64 + 4 * S, RH = 32 + 4 * S;
-    hipLaunchKernelGGL(k_df_sor_fused<S>, dim3((g.w + 63) / 64, (g.h + 31) / 32, B), dim3(256), (size_t)3 * RW * RH * sizeof(float), s, d, g, omega);
+    hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 256>), dim3((g.w + 63) / 64, (g.h + 31) / 32, B), dim3(256), (size_t)3 * RW * RH * sizeof(float), s, d, g, omega, S);
+}
+
+// levels that fit one 96 x 96 region: all sweeps of a fixed-point iteration in ONE launch, one block of 1024 threads per pair
+constexpr int DF_WHOLE = 96;
+void launch_sor_whole(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
+{
+    constexpr size_t shm = (size_t)(3 * DF_WHOLE * DF_WHOLE + DF_WHOLE / 2 + 4) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<0, DF_WHOLE, DF_WHOLE, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_df_sor_fused<0, DF_WHOLE, DF_WHOLE, 1024>), dim3(1, 1, B), dim3(1024), shm, s, d, g, omega, sweeps);
 }
 
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
@@ -633,6 +647,22 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
         hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
         hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
         int left = h->DP.sor_iterations;
+        if (h->sor_whole && fuse > 0 && left > 0 && g.w <= DF_WHOLE && g.h <= DF_WHOLE) {
+            ProfEv* pe = nullptr;
+            if (h->profile) {
+                if (h->prof_used == h->prof_pool.size()) {
+                    ProfEv ne;
+                    if (hipEventCreate(&ne.a) == hipSuccess && hipEventCreate(&ne.b) == hipSuccess) h->prof_pool.push_back(ne);
+                }
+                if (h->prof_used < h->prof_pool.size()) { pe = &h->prof_pool[h->prof_used++]; (void)hipEventRecord(pe->a, s); }
+            }
+            ++h->iter_launches;
+            h->df_sor_bytes += (double)left * g.w * g.h * B * 40.0;
+            launch_sor_whole(d, g, B, c.omega, left, s);
+            if (pe) (void)hipEventRecord(pe->b, s);
+            std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
+            left = 0;
+        }
         while (left > 0) {
             const int n = fuse > 0 ? (left < fuse ? left : fuse) : 0;
             if (n == 0) {     // one colour per launch, in place
@@ -853,7 +883,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1102,6 +1132,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
+    else if (n == "sor_whole") h->sor_whole = value;
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;

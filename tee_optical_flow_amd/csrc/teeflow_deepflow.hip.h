@@ -209,14 +209,17 @@ __global__ __launch_bounds__(256) void k_df_sor(DfBufs d, Geom g, int color, flo
 // lanes have work (no idle colour), and the slot's geometry flags are computed once.
 // LDS holds even-x and odd-x pixels in separate arrays (same-colour pixels of a row are then contiguous: no 2-way bank
 // conflicts of a stride-2 access), and a slot's two pixels are fetched / written back with one 8-byte access per plane.
-template <int S>
-__global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float omega)
+// S > 0: S sweeps on TW x TH tiles with a 2S halo.  S == 0: the region IS the image (W <= TW, H <= TH; one block per pair,
+// no halo, nothing recomputed) and `nsw` sweeps -- a whole fixed-point iteration's SOR -- run in one launch.
+template <int S, int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_df_sor_fused(DfBufs d, Geom g, float omega, int nsw)
 {
-    constexpr int HL = 2 * S, TW = 64, TH = 32, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + 255) / 256;
+    constexpr int HL = 2 * S, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + NT - 1) / NT;
+    constexpr int PAD = S == 0 ? HW + 4 : 0;     // whole-image form: row 0 is updated, its (unused) "row above" address must stay inside LDS
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS planes [x parity][ry * HW + rx / 2]: du at (0 + parity) * NSLOT, dv at (2 + parity) * NSLOT, weights at (4 + parity) * NSLOT
     // (addressed by offset: pointer arrays initialised from the LDS base trip a static-initializer limitation of the compiler)
-    constexpr int ODU = 0, ODV = 2 * NSLOT, OWG = 4 * NSLOT;
+    constexpr int ODU = PAD, ODV = PAD + 2 * NSLOT, OWG = PAD + 4 * NSLOT;
     const int b = blockIdx.z, x0 = blockIdx.x * TW - HL, y0 = blockIdx.y * TH - HL;   // x0 is even
     const int W = g.w, H = g.h, pitch = g.pitch;
     const size_t po = (size_t)b * g.splane;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float om
     float a11[2][NS], a12[2][NS], a22[2][NS], b1[2][NS], b2[2][NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        const int q = threadIdx.x + k * 256;
+        const int q = threadIdx.x + k * NT;
         const int ry = q / HW, qx = q - ry * HW;
         const int gy = y0 + ry, gxe = x0 + 2 * qx;
         float2 vdu = make_float2(0, 0), vdv = vdu, vw = vdu, v11 = make_float2(1, 1), v12 = vdu, v22 = v11, vb1 = vdu, vb2 = vdu;
@@ -267,15 +270,16 @@ __global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float om
         }
     }
     __syncthreads();
+    const int sweeps = S > 0 ? S : nsw;
 #pragma unroll 1
-    for (int sw = 0; sw < S; ++sw) {
+    for (int sw = 0; sw < sweeps; ++sw) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const unsigned f = flg[c][k];
                 if (f & 1u) {
-                    const int q = threadIdx.x + k * 256;
+                    const int q = threadIdx.x + k * NT;
                     const int par = (f >> 6) & 1;
                     // own-parity arrays hold the pixel and its vertical neighbours; the other parity holds left / right
                     float* duA = smem + ODU + par * NSLOT; float* dvA = smem + ODV + par * NSLOT;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void k_df_sor_fused(DfBufs d, Geom g, float om
     for (int k = 0; k < NS; ++k) {
         const unsigned f0 = flg[0][k], f1 = flg[1][k];
         if ((f0 | f1) & 32u) {
-            const int q = threadIdx.x + k * 256;
+            const int q = threadIdx.x + k * NT;
             const int ry = q / HW, qx = q - ry * HW;
             const size_t i = po + (size_t)(y0 + ry) * pitch + (x0 + 2 * qx);   // other tiles still read (du, dv) of this tile as halo
             if ((f0 & f1) & 32u) {
