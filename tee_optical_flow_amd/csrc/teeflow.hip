@@ -96,6 +96,7 @@ struct tf_handle {
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
+    int tile_max_w = 0;          // levels this narrow or narrower always take the tile kernels (experiment: see DESIGN section 8)
     int sor_whole = 1;           // DeepFlow: levels up to 96 x 96 run a whole fixed-point iteration's SOR in one launch
     int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
     int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
@@ -258,7 +259,7 @@ struct StageTotals {
 // full-width strips need W <= max_strip_width (at most 2048: one quad per thread, 512 threads) and enough rows*pairs to fill 256 CUs; tiny launches (single-pair latency mode) keep the tiles
 bool rows_ok(const tf_handle* h, const Geom& g, int B)
 {
-    return h->iter_variant >= 1 && g.w <= h->max_strip_width && (long long)g.h * B >= h->min_rows_work;
+    return h->iter_variant >= 1 && g.w <= h->max_strip_width && g.w > h->tile_max_w && (long long)g.h * B >= h->min_rows_work;
 }
 
 // Block shape of the row-strip kernels: QX quads per row, RY = floor(256/QX) rows per step, 256 threads.
@@ -883,7 +884,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->tile_max_w = h->tile_max_w;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1132,6 +1133,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
+    else if (n == "tile_max_w") h->tile_max_w = value;
     else if (n == "sor_whole") h->sor_whole = value;
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
