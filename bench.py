@@ -198,13 +198,13 @@ def main():
                                  "and the kernel is bound by fp32/fp64 VALU issue (see DESIGN.md section 4)",
                          "measured_on": f"{a.steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
         else:
-            ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused<3> (red-black SOR, 3 sweeps per launch on LDS tiles; dominant)",
+            ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused (red-black SOR, 4 sweeps per launch on 64x32 LDS tiles, 1024-thread blocks; whole levels up to 96x96 in one launch; dominant)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms, "launches": acc["iter_launches"],
                     "bytes_per_px_sweep": 40,
                     "note": "achieved = executed pixel-sweeps x 40 B (compulsory traffic of ONE red-black sweep: du, dv, weight, A11, A12, "
                             "A22, b1, b2 read, du, dv written) / summed launch time, one HIP event pair per launch, single lane; the kernel "
-                            "fuses 3 sweeps per launch on LDS tiles, so about a third of that goes through HBM and the kernel is bound by "
+                            "fuses 4 sweeps per launch on LDS tiles (25 on levels that fit one block), so about a quarter of that goes through HBM and the kernel is bound by "
                             "LDS latency and the two IEEE divisions per update"}
         out = {
             "metric": "frame-pairs/sec @512x512 " + ("DualTVL1" if a.algo == "TVL1" else "DeepFlow"), "value": pairs / dt, "unit": "frame-pairs/s",

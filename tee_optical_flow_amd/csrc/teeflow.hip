@@ -97,6 +97,8 @@ struct tf_handle {
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
     int tile_max_w = 0;          // levels this narrow or narrower always take the tile kernels (experiment: see DESIGN section 8)
+    int sor_nt = 1024;           // DeepFlow SOR tile kernel: threads per block (256 | 512 | 1024).  Fewer slots per thread = fewer
+                                 // registers (167 -> 95 -> 60 VGPRs at 3-4 sweeps) = 3 -> 4 -> 8 waves per SIMD: 411 / 470 / 491 pairs/s
     int sor_whole = 1;           // DeepFlow: levels up to 96 x 96 run a whole fixed-point iteration's SOR in one launch
     int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
     int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
@@ -111,7 +113,8 @@ struct tf_handle {
     float* wsum = nullptr; size_t wsum_cap = 0;
     float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
-    int sor_fuse = 3;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); 3 measured best
+    int sor_fuse = 4;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); with
+                                 // 1024-thread blocks 4 is best (64 pairs @512^2: 460 / 491 / 378 pairs/s for 3 / 4 / 5)
     int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
                                  // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
     int min_rows_work = 8192;    // rows*pairs of a level below which the tile kernels are used (measured at 512^2 with k_iter2_tile: 16 pairs
@@ -614,10 +617,14 @@ void df_gauss3(float sigma, float* k0, float* k1)
 }
 
 template <int S>
-void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s)
+void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s, int nt = 256)
 {
     constexpr int RW = 64 + 4 * S, RH = 32 + 4 * S;
-    hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 256>), dim3((g.w + 63) / 64, (g.h + 31) / 32, B), dim3(256), (size_t)3 * RW * RH * sizeof(float), s, d, g, omega, S);
+    const dim3 grid((g.w + 63) / 64, (g.h + 31) / 32, B);
+    const size_t shm = (size_t)3 * RW * RH * sizeof(float);
+    if (nt == 1024) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024>), grid, dim3(1024), shm, s, d, g, omega, S);
+    else if (nt == 512) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 512>), grid, dim3(512), shm, s, d, g, omega, S);
+    else hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 256>), grid, dim3(256), shm, s, d, g, omega, S);
 }
 
 // levels that fit one 96 x 96 region: all sweeps of a fixed-point iteration in ONE launch, one block of 1024 threads per pair
@@ -683,11 +690,11 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             ++h->iter_launches;
             h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;   // one sweep: 8 planes read + du, dv written
             switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
-                case 1: launch_sor_fused<1>(d, g, B, c.omega, s); break;
-                case 2: launch_sor_fused<2>(d, g, B, c.omega, s); break;
-                case 3: launch_sor_fused<3>(d, g, B, c.omega, s); break;
-                case 4: launch_sor_fused<4>(d, g, B, c.omega, s); break;
-                default: launch_sor_fused<5>(d, g, B, c.omega, s); break;
+                case 1: launch_sor_fused<1>(d, g, B, c.omega, s, h->sor_nt); break;
+                case 2: launch_sor_fused<2>(d, g, B, c.omega, s, h->sor_nt); break;
+                case 3: launch_sor_fused<3>(d, g, B, c.omega, s, h->sor_nt); break;
+                case 4: launch_sor_fused<4>(d, g, B, c.omega, s, h->sor_nt); break;
+                default: launch_sor_fused<5>(d, g, B, c.omega, s, h->sor_nt); break;
             }
             if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
@@ -884,7 +891,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->tile_max_w = h->tile_max_w;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1135,6 +1142,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "slots") h->slots_override = value;
     else if (n == "tile_max_w") h->tile_max_w = value;
     else if (n == "sor_whole") h->sor_whole = value;
+    else if (n == "sor_nt") h->sor_nt = value == 1024 ? 1024 : (value == 512 ? 512 : 256);
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;

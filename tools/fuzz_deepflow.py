@@ -25,7 +25,8 @@ def main():
         if rng.random() < 0.25:
             I1s[0] = I0s[0]
         eng = T.DenseFlow(algo="deepflow", max_batch=int(rng.choice([B, max(1, B // 2)])))
-        eng.set_tuning("sor_fuse", int(rng.choice([0, 1, 2, 3, 5])))
+        eng.set_tuning("sor_fuse", int(rng.choice([0, 1, 2, 3, 4, 5])))
+        eng.set_tuning("sor_nt", int(rng.choice([256, 512, 1024])))
         flows = eng.calc_pairs(I0s, I1s)
         ok = True
         for b in sorted(set([0, B - 1])):
