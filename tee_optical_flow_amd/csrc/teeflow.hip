@@ -628,16 +628,23 @@ void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStr
 }
 
 // levels that fit one 96 x 96 region: all sweeps of a fixed-point iteration in ONE launch, one block of 1024 threads per pair
+// (a 64 x 64 region for the smallest levels: 2 instead of 5 slots per thread)
 constexpr int DF_WHOLE = 96;
-void launch_sor_whole(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
+template <int RGN>
+void launch_sor_whole_t(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
 {
-    constexpr size_t shm = (size_t)(3 * DF_WHOLE * DF_WHOLE + DF_WHOLE / 2 + 4) * sizeof(float);
+    constexpr size_t shm = (size_t)(3 * RGN * RGN + RGN / 2 + 4) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<0, DF_WHOLE, DF_WHOLE, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<0, RGN, RGN, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr = true;
     }
-    hipLaunchKernelGGL((k_df_sor_fused<0, DF_WHOLE, DF_WHOLE, 1024>), dim3(1, 1, B), dim3(1024), shm, s, d, g, omega, sweeps);
+    hipLaunchKernelGGL((k_df_sor_fused<0, RGN, RGN, 1024>), dim3(1, 1, B), dim3(1024), shm, s, d, g, omega, sweeps);
+}
+void launch_sor_whole(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
+{
+    if (g.w <= 64 && g.h <= 64) launch_sor_whole_t<64>(d, g, B, omega, sweeps, s);
+    else launch_sor_whole_t<DF_WHOLE>(d, g, B, omega, sweeps, s);
 }
 
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
