@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_df_sor(DfBufs d, Geom g, int color, flo
 // S > 0: S sweeps on TW x TH tiles with a 2S halo.  S == 0: the region IS the image (W <= TW, H <= TH; one block per pair,
 // no halo, nothing recomputed) and `nsw` sweeps -- a whole fixed-point iteration's SOR -- run in one launch.
 template <int S, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_df_sor_fused(DfBufs d, Geom g, float omega, int nsw)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 && S > 0 ? 8 : 1, NT == 1024 && S > 0 ? 8 : 8))) void k_df_sor_fused(DfBufs d, Geom g, float omega, int nsw)
 {
     constexpr int HL = 2 * S, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + NT - 1) / NT;
     constexpr int PAD = S == 0 ? HW + 4 : 0;     // whole-image form: row 0 is updated, its (unused) "row above" address must stay inside LDS
