@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- frame-pairs/s of the MI355X DualTVL1 path (BASELINE.json metric).
+"""bench.py -- frame-pairs/s of the MI355X DualTVL1 path (BASELINE.json metric), plus a DeepFlow leg (BASELINE configs[3]).
 
 One "step" = one pass of the hot path over one batch: every rank solves `--batch` (default 128) independent
 512x512 uint8 frame pairs (synthetic "speckle-warp v1"; pair shape of BASELINE configs[1],
@@ -7,12 +7,22 @@ per-GPU shard size of configs[2]) with all-default DualTVL1 (lambda 0.15), input
 for N > 1 -- the (u,v) fields are all-gathered over RCCL (the one exchange step north_star names), overlapped
 with the next step's compute.  value = pairs all ranks solved / max-over-ranks wall time.
 
+The default N=1 run then measures BASELINE configs[3] (OF_algo='deepflow', the algorithm the reference's own CLI
+hard-codes, calculate_optical_flow.py:735-739) the same way on 64 pairs and reports it under "deepflow" in the
+same JSON line.
+
+Everything that is not GPU work (synthetic inputs, the optional `--pmc` counter passes, which run this script as a
+child under rocprofv3) happens BEFORE the first GPU call, so no process is ever started from a GPU-initialised one.
+
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,9 +32,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming ceiling)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured streaming ceiling)
+HBM_STREAM_GBS = 6290.0
+SIMDS = 256 * 4         # 256 CUs x 4 SIMDs
+TVL1_KERNEL = "k_iter2_rows"
+DF_KERNEL = "k_df_sor_fused"
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# inputs (CPU only; runs before any GPU call)
+# ---------------------------------------------------------------------------------------------------------------
 def _gen_pair(args):
     from tee_optical_flow_amd.synth import speckle_pair
     seed, H, W = args
@@ -32,19 +49,134 @@ def _gen_pair(args):
     return I0, I1
 
 
-def make_inputs(seeds, H, W):
-    import multiprocessing as mp
+def under_profiler():
+    """rocprofv3 preloads its tool library, which initialises the GPU before main(): no child processes then."""
+    pre = os.environ.get("LD_PRELOAD", "").lower()
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def make_inputs(seeds, H, W, allow_pool=True):
+    """[I0s, I1s] uint8 [B,H,W].  Cached under $TMPDIR (the generator is deterministic); a process pool only when
+    nothing in this process has touched the GPU and no profiler is attached."""
+    seeds = list(seeds)
+    key = hashlib.sha1(repr((seeds, H, W, "speckle-warp v1")).encode()).hexdigest()[:16]
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"teeflow_bench_inputs_{key}.npz")
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            if z["I0s"].shape == (len(seeds), H, W):
+                return z["I0s"], z["I1s"]
+        except (OSError, ValueError, KeyError):
+            pass
     n = min(8, len(seeds), os.cpu_count() or 1)
-    if n > 1:
+    if allow_pool and n > 1 and not under_profiler():
+        import multiprocessing as mp
         with mp.get_context("spawn").Pool(n) as pool:
             res = pool.map(_gen_pair, [(s, H, W) for s in seeds])
     else:
         res = [_gen_pair((s, H, W)) for s in seeds]
-    return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+    I0s, I1s = np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+    try:
+        tmp = cache + f".{os.getpid()}.npz"     # np.savez appends nothing: the name already ends in .npz
+        np.savez(tmp, I0s=I0s, I1s=I1s)
+        os.replace(tmp, cache)
+    except OSError:
+        pass
+    return I0s, I1s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# evidence kept under profiles/: PMC traffic and ISA statistics, each tied to the kernel source it was taken from
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_source_fingerprint():
+    """sha256 over the HIP sources + the build recipe: a stored PMC / ISA record is used only for the build it came from."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "tee_optical_flow_amd", "csrc", "*"))):
+        if p.endswith((".hip", ".h", "Makefile")):
+            with open(p, "rb") as f:
+                h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def stored_record(fname, kernel):
+    """(record, why_not) from profiles/<fname> for `kernel`, accepted only when its source fingerprint is this build's."""
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None, f"profiles/{fname} missing or unreadable"
+    if not rec:
+        return None, f"profiles/{fname} has no record for {kernel}"
+    fp = kernel_source_fingerprint()
+    if rec.get("source_fingerprint") != fp:
+        return None, (f"profiles/{fname} was taken from kernel sources {rec.get('source_fingerprint')} (round {rec.get('round')}), "
+                      f"this build is {fp}: not used")
+    return rec, None
+
+
+def pmc_child_passes(algo, out_dir, tag="live"):
+    """`--pmc`: run this script as a CHILD under rocprofv3 (one pass per counter, as MI355X_MICROARCH.md prescribes) and
+    return {'fetch_kb','write_kb','launches'} averaged per launch of the dominant kernel.  Must be called before this
+    process touches the GPU."""
+    import csv
+    kern = TVL1_KERNEL if algo == "TVL1" else DF_KERNEL
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out_dir, f"pmc_{tag}_{algo}_{ctr}")
+        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-include-regex", kern, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile",
+               "--lanes", "1", "--no-deepflow", "--algo", algo] + (["--batch", "64"] if algo != "TVL1" else [])
+        env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+        r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        if r.returncode != 0:
+            return {"error": f"rocprofv3 --pmc {ctr} failed rc={r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
+        per = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == ctr and kern in row["Kernel_Name"]:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+        if not per:
+            return {"error": f"no {ctr} rows for {kern}"}
+        v = list(per.values())
+        res["fetch_kb" if ctr == "FETCH_SIZE" else "write_kb"] = sum(v) / len(v)
+        res["launches"] = len(v)
+        res["command"] = (f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one pass each) --kernel-include-regex {kern} -- python3 bench.py "
+                          + " ".join(cmd[cmd.index("--steps"):]))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle; test infrastructure used here only as the reported baseline and the parity checker)
+# ---------------------------------------------------------------------------------------------------------------
+def cv2_baseline(I0s, I1s, n_sample, algo):
+    """BASELINE.md tier B2: real OpenCV on this box's host cores -- only when cv2 happens to be importable (probed, never
+    required, never installed).  Returns (record, flows) or (None, None)."""
+    import importlib.util
+    if importlib.util.find_spec("cv2") is None:
+        return None, None
+    try:
+        import cv2
+        if algo == "TVL1":
+            m = cv2.optflow.createOptFlow_DualTVL1()       # reference calculate_optical_flow.py:577-578
+            m.setLambda(0.15)
+        else:
+            m = cv2.optflow.createOptFlow_DeepFlow()       # reference :568
+        threads = cv2.getNumThreads()
+        m.calc(I0s[0], I1s[0], None)
+        t0 = time.perf_counter()
+        flows = [m.calc(I0s[i], I1s[i], None) for i in range(n_sample)]
+        dt = time.perf_counter() - t0
+        return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "opencv", "cv2_version": cv2.__version__,
+                "sample": f"{n_sample} of the benchmark's pairs, 1 warm-up, cv2.optflow {'DualTVL1 (lambda 0.15)' if algo == 'TVL1' else 'DeepFlow'}"}, flows
+    except Exception as e:   # an OpenCV build without the contrib optflow module, ...
+        return {"error": f"cv2 present but unusable: {e!r}"}, None
 
 
 def cpu_baseline(I0s, I1s, n_sample, algo="TVL1"):
-    """Oracle (CPU restatement, NOT OpenCV) timed on this box's host cores on a bounded sample of the same workload."""
+    """Oracle (CPU restatement, NOT OpenCV) timed on this box's host cores on a bounded sample of the same workload:
+    all granted cores, and one thread as the median over >= 3 pairs."""
     from oracle import oracle as O
     threads = O.effective_cpus()
     O.set_num_threads(threads)
@@ -55,9 +187,255 @@ def cpu_baseline(I0s, I1s, n_sample, algo="TVL1"):
     for i in range(n_sample):
         flows.append(calc(I0s[i], I1s[i]))
     dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{n_sample} of the benchmark's 512x512 pairs (seeds 0..{n_sample - 1}), 1 warm-up, "
-                      f"oracle/{'tvl1' if algo == 'TVL1' else 'deepflow'}_oracle.c with {threads} OpenMP threads; restatement, not OpenCV"}, flows
+    O.set_num_threads(1)
+    one = []
+    for i in range(min(3, len(I0s))):
+        t1 = time.perf_counter()
+        calc(I0s[i], I1s[i])
+        one.append(time.perf_counter() - t1)
+    O.set_num_threads(threads)
+    rec = {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+           "sample": f"{n_sample} of the benchmark's 512x512 pairs (seeds 0..{n_sample - 1}), 1 warm-up, "
+                     f"oracle/{'tvl1' if algo == 'TVL1' else 'deepflow'}_oracle.c with {threads} OpenMP threads; restatement, not OpenCV",
+           "one_thread_pairs_per_s_median_of_3": 1.0 / float(np.median(one))}
+    return rec, flows
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one measured leg
+# ---------------------------------------------------------------------------------------------------------------
+def launch_profile(eng):
+    """Per-launch records of the last profiled single-lane solve: level, warp, first iteration, ms."""
+    import ctypes as C
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    n = L.tf_dbg_launch_profile(eng._h, None, None, None, None, 0)
+    lv, wp, it = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+    ms = np.zeros(max(n, 1), np.float32)
+    ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+    L.tf_dbg_launch_profile(eng._h, ptr(lv), ptr(wp), ptr(it), ptr(ms), n)
+    return lv[:n], wp[:n], it[:n], ms[:n]
+
+
+def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, local_rank, live_pmc=None, cpu_sample=8):
+    import tee_optical_flow_amd as T
+    H = W = a.size
+    frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)       # [2B,H,W] u8, resident in HBM
+    flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    gdev = dev if a.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
+    eng = T.DenseFlow(device_id=local_rank, max_batch=B, algo=algo)
+    eng.set_tuning("lanes", a.lanes)
+    tuning = [kv.split("=") for kv in a.tuning.split(",") if kv]
+    for k, v in tuning:
+        eng.set_tuning(k, int(v))
+    # The engine runs on its own non-blocking HIP stream and every call is host-synchronous: when it returns the flows are
+    # complete, so the RCCL all-gather (torch's stream) may start at once.  The opposite direction needs an explicit host
+    # wait: Work.wait() only orders torch's CURRENT STREAM behind the collective, it does not block the host, and the
+    # engine's stream is not ordered against either -- so before a buffer is solved into again the host waits until the
+    # all-gather that read it has really finished.
+    p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
+    pending = [None, None]
+
+    def retire(buf):
+        if pending[buf] is not None:
+            pending[buf].wait()
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+            pending[buf] = None
+
+    def step(k):
+        buf = k & 1
+        retire(buf)
+        st = eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
+        if world > 1:
+            src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
+        return st
+
+    def drain():
+        retire(0)
+        retire(1)
+
+    def fence():
+        drain()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(warmup):
+        step(k)
+    fence()
+    t0 = time.perf_counter()
+    acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0,
+           "timed_iter_bytes": 0.0}
+    for k in range(steps):
+        st = step(warmup + k)
+        acc["total_bytes"] += st["total_bytes"]; acc["inner"] += st["inner_iters_total"]; acc["outer"] += st["outer_iters_total"]
+        acc["ms_device"] += st["ms_device"]; acc["timed_iter_bytes"] += st["iter_bytes"]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    gather_ok = None
+    if world > 1:
+        # every rank's shard must have arrived intact everywhere: compare checksums of the gathered segments with the
+        # checksums the owning ranks computed locally (last timed step)
+        last = (warmup + steps - 1) & 1
+        mine = flows[last].double().sum().reshape(1).to(gdev)
+        sums = torch.empty(world, dtype=torch.float64, device=gdev)
+        dist.all_gather_into_tensor(sums, mine)
+        seg = gathered[last].view(world, -1).double().sum(1)
+        gather_ok = bool(torch.equal(seg.cpu(), sums.cpu()))
+    # Roofline leg: the SAME K steps again, one lane, with every launch of the dominant kernel bracketed by a HIP event
+    # pair on the engine's stream.  Kept out of the timed region above (the event records cost a few % of a step).
+    prof = None
+    if not a.no_profile:
+        eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include the other lane's kernels
+        eng.set_profile(1)
+        for k in range(steps):
+            st = step(warmup + steps + k)
+            acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
+        drain()
+        torch.cuda.synchronize(dev)
+        if algo == "TVL1":
+            prof = launch_profile(eng)
+        eng.set_profile(0)
+        eng.set_tuning("lanes", a.lanes)
+
+    out = None
+    if rank == 0:
+        pairs = world * B * steps
+        unit_bytes = 60.0 if algo == "TVL1" else 40.0          # bytes tf_stats.iter_bytes charges per px-iteration / px-sweep
+        launches = max(acc["iter_launches"], 1)
+        avg_launch_ms = acc["iter_ms"] / launches if acc["iter_ms"] > 0 else None
+        units_per_launch = acc["iter_bytes"] / unit_bytes / launches           # px-iterations (px-sweeps) per launch, averaged
+        kern = TVL1_KERNEL if algo == "TVL1" else DF_KERNEL
+        # ---- HBM traffic of the dominant kernel: live PMC passes (--pmc) or the stored passes of THIS build --------
+        traffic = None
+        traffic_source = None
+        if live_pmc and "fetch_kb" in live_pmc and "write_kb" in live_pmc:
+            traffic = (2.0 * live_pmc["fetch_kb"] + live_pmc["write_kb"]) * 1024.0
+            traffic_source = {"kind": "live", "command": live_pmc.get("command"), "launches_profiled": live_pmc.get("launches"),
+                              "fetch_size_kb_mean": live_pmc["fetch_kb"], "write_size_kb_mean": live_pmc["write_kb"]}
+        else:
+            rec, why = stored_record("hbm_traffic.json", kern)
+            if rec:
+                traffic = rec["bytes_per_launch"]
+                traffic_source = {"kind": "stored", "file": "profiles/hbm_traffic.json", "round": rec.get("round"),
+                                  "source_fingerprint": rec.get("source_fingerprint"), "command": rec.get("command"),
+                                  "launches_profiled": rec.get("launches_profiled"), "note": "PMC passes of this same kernel build, not of this run"}
+            else:
+                traffic_source = {"kind": "none", "why": (live_pmc or {}).get("error") or why}
+        comp_bytes = 30.0 if algo == "TVL1" else None      # compulsory bytes per px-iteration of the fused two-iteration kernel
+        secs = avg_launch_ms / 1e3 if avg_launch_ms else None
+        if traffic is not None and secs:
+            achieved, basis = traffic / 1e9 / secs, "measured HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, gfx950 read correction) / mean launch time"
+        elif secs and comp_bytes:
+            achieved, basis = units_per_launch * comp_bytes / 1e9 / secs, "no PMC pass of this build: compulsory bytes of the fused kernel (30 B per px-iteration) / mean launch time"
+        elif secs:
+            achieved, basis = units_per_launch * unit_bytes / 4 / 1e9 / secs, "no PMC pass of this build: 40 B per px-sweep / 4 sweeps fused per launch / mean launch time"
+        else:
+            achieved, basis = None, "profiling off"
+        roof = {"bound": "hbm", "limiter": "valu-issue" if algo == "TVL1" else "lds-latency",
+                "kernel": kern + (" (tvl1_iter: two inner iterations per launch, full-width row strips)" if algo == "TVL1" else
+                                  " (red-black SOR, 4 sweeps per launch on 64x32 LDS tiles; 25 on levels that fit one block)"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "frac_of_streaming_ceiling": achieved / HBM_STREAM_GBS if achieved else None,
+                "traffic": traffic, "traffic_source": traffic_source, "achieved_basis": basis,
+                "avg_launch_ms": avg_launch_ms, "launches": acc["iter_launches"], "launches_per_step": acc["iter_launches"] / max(steps, 1),
+                ("px_iterations_per_launch" if algo == "TVL1" else "px_sweeps_per_launch"): units_per_launch,
+                "measured_on": f"{steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
+        rate = units_per_launch / secs if secs else None
+        if algo == "TVL1":
+            roof["notional_GBps_60B"] = rate * 60.0 / 1e9 if rate else None     # one-iteration-per-pass kernel's compulsory traffic
+            roof["notional_GBps_88B"] = rate * 88.0 / 1e9 if rate else None     # SURVEY.md section 8(d): two-kernel K_A/K_B formulation
+            roof["notional_note"] = ("what kernels that make one HBM pass per inner iteration would have had to move at this rate; the shipped kernel "
+                                     "makes one pass per TWO iterations, so these exceed its real traffic and are not roofline fractions")
+            full = None
+            if prof is not None and len(prof[3]):
+                lv, wp, it, ms = prof
+                m = (lv == 0) & (it == 0) & (ms > 0)             # first launch of a level-0 stage: all B pairs iterate, 2 iterations
+                if m.any():
+                    full = float(np.median(B * H * W * 2.0 / (ms[m] * 1e-3)))
+            isa, why = stored_record("isa_stats.json", kern)
+            valu = {"px_iterations_per_s_all_launches": rate, "px_iterations_per_s_full_launches": full}
+            if isa:
+                ipp = isa["valu_insts_per_wave_step"] / isa["px_iterations_per_wave_step"]
+                valu.update({"valu_insts_per_px_iteration": ipp, "vgprs": isa.get("vgprs"), "waves_per_simd": isa.get("waves_per_simd"),
+                             "isa_source": "profiles/isa_stats.json (disassembly of this build's main loop)",
+                             "simd_cycles_per_valu_inst_full_launches": (a.clock_ghz * 1e9 * SIMDS / (full * ipp) if full else None),
+                             "clock_ghz_assumed": a.clock_ghz})
+            else:
+                valu["isa_source"] = why
+            roof["valu"] = valu
+        out = {
+            "metric": "frame-pairs/sec @512x512 " + ("DualTVL1" if algo == "TVL1" else "DeepFlow"), "value": pairs / dt, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
+                                   "configs[2] per-GPU shard), speckle-warp v1 seeds rank*B..; "
+                                   + ("DualTVL1 all defaults, lambda 0.15, 5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; "
+                                      if algo == "TVL1" else
+                                      "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
+                                   + "inputs resident in HBM; "
+                                   + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
+                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}", "lanes_per_gpu": a.lanes},
+            # data-independent rate of the whole job: executed pixel-iterations (pixel-sweeps) per second of the timed region
+            ("px_iterations_per_s" if algo == "TVL1" else "px_sweeps_per_s"): world * acc["timed_iter_bytes"] / unit_bytes / dt,
+            "roofline": roof,
+            "whole_solve_algorithmic_GBps": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
+        }
+        if algo == "TVL1":
+            out["executed_inner_iterations_per_pair"] = acc["inner"] / (B * steps)
+            out["executed_outer_iterations_per_pair"] = acc["outer"] / (B * steps)
+            out["data_dependence_note"] = ("pairs/s depends on how early the synthetic pairs converge (executed inner iterations per pair above, of a "
+                                           "possible 7500); px_iterations_per_s does not")
+        if gather_ok is not None:
+            out["allgather_checksums_match"] = gather_ok
+        # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
+        lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1, algo=algo)
+        for k, v in tuning:
+            lat_eng.set_tuning(k, int(v))
+        f1 = torch.empty((1, H, W, 2), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
+        torch.cuda.synchronize(dev)
+        nlat = 10 if algo == "TVL1" else 4
+        tl = time.perf_counter()
+        for _ in range(nlat):
+            lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
+        torch.cuda.synchronize(dev)
+        out["latency_ms_single_pair"] = (time.perf_counter() - tl) / nlat * 1e3
+        lat_eng.close()
+        # the same step through the host-pointer entry point (PCIe in and out included) -- reported beside, never as `value`
+        eng.calc_pairs(I0s, I1s)                   # result arrays come from the engine's pinned pool: this call fills it
+        tp = time.perf_counter()
+        eng.calc_pairs(I0s, I1s)
+        out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
+        if world == 1 and not a.no_cpu_baseline:
+            n = min(cpu_sample, B)
+            cb, ref = cpu_baseline(I0s, I1s, n, algo)
+            out["cpu_baseline"] = cb
+            last = warmup + steps - 1 + (0 if a.no_profile else steps)
+            got = flows[last & 1][:n].cpu().numpy()
+            out["parity_vs_oracle_max_abs_diff_on_cpu_sample"] = max(float(np.abs(got[i] - ref[i]).max()) for i in range(n))
+            cvb, cvf = cv2_baseline(I0s, I1s, min(n, 4), algo)
+            if cvb is None:
+                out["opencv_baseline"] = "cv2 not importable on this box (importlib.util.find_spec('cv2') is None): BASELINE.md tier B2 skipped; parity vs OpenCV stays unpinned"
+            else:
+                out["opencv_baseline"] = cvb
+                if cvf is not None:
+                    epe = [float(np.sqrt(((got[i] - cvf[i]) ** 2).sum(-1)).mean()) for i in range(len(cvf))]
+                    out["mean_epe_vs_opencv"] = float(np.mean(epe))
+                    out["cpu_baseline"] = cvb       # the real thing replaces the restatement as THE baseline
+                    out["cpu_baseline_port"] = cb
+    eng.close()
+    del frames, flows, gathered
+    return out
 
 
 def main():
@@ -70,16 +448,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket tvl1_iter launches with HIP events")
-    ap.add_argument("--algo", default="TVL1", choices=["TVL1", "deepflow"], help="BASELINE configs[1..2] (TVL1, default) or configs[3] (deepflow)")
+    ap.add_argument("--algo", default="TVL1", choices=["TVL1", "deepflow"], help="BASELINE configs[1..2] (TVL1, default) or configs[3] (deepflow) as the main leg")
+    ap.add_argument("--no-deepflow", action="store_true", help="skip the DeepFlow leg the default N=1 TVL1 run appends")
+    ap.add_argument("--deepflow-batch", type=int, default=64)
+    ap.add_argument("--deepflow-steps", type=int, default=2)
+    ap.add_argument("--pmc", action="store_true", help="N=1 only: first run the FETCH_SIZE / WRITE_SIZE counter passes of this command as child "
+                                                       "processes under rocprofv3 (adds ~1-2 min), so roofline.traffic is measured in this run")
+    ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_live"))
     ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--tuning", default="", help="experiments only: engine knobs as name=value,... (tf_set_tuning); empty = shipped defaults")
+    ap.add_argument("--clock-ghz", type=float, default=2.4, help="shader clock assumed for the cycles-per-instruction figure (max clock; DESIGN.md notes 2.32 held under load)")
     a = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import tee_optical_flow_amd as T
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,6 +470,20 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    # ---- CPU-only preparation: nothing below this block may start a process ------------------------------------
+    B, H, W = a.batch, a.size, a.size
+    I0s, I1s = make_inputs(range(rank * B, (rank + 1) * B), H, W)          # rank r owns pairs [rB, (r+1)B): no data-path exchange
+    want_df = a.algo == "TVL1" and world == 1 and not a.no_deepflow
+    DB = min(a.deepflow_batch, B)
+    live = {}
+    if a.pmc and world == 1 and not under_profiler():
+        live[a.algo] = pmc_child_passes(a.algo, a.pmc_dir)
+        if want_df:
+            live["deepflow"] = pmc_child_passes("deepflow", a.pmc_dir)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     if a.share_device:
@@ -102,161 +497,16 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
-    B, H, W = a.batch, a.size, a.size
-    seeds = list(range(rank * B, (rank + 1) * B))      # rank r owns pairs [rB, (r+1)B): no data-path exchange
-    I0s, I1s = make_inputs(seeds, H, W)
-    frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)       # [2B,H,W] u8, resident in HBM
-    flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)]
-    gdev = dev if a.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
-    eng = T.DenseFlow(device_id=local_rank, max_batch=B, algo=a.algo)
-    eng.set_tuning("lanes", a.lanes)
-    tuning = [kv.split("=") for kv in a.tuning.split(",") if kv]
-    for k, v in tuning:
-        eng.set_tuning(k, int(v))
-    # the engine runs on its own non-blocking HIP stream (its per-launch events are recorded there); every call is
-    # host-synchronous, so torch-side consumers (the RCCL all-gather) may start right after it returns
-    p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
-
-    pending = [None, None]
-
-    def step(k):
-        buf = k & 1
-        if pending[buf] is not None:       # the all-gather that last read this buffer must be done
-            pending[buf].wait()
-            pending[buf] = None
-        st = eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
-        if world > 1:
-            src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
-            pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
-        return st
-
-    def drain():
-        for i in range(2):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
-
-    for k in range(a.warmup):
-        step(k)
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0}
-    for k in range(a.steps):
-        st = step(a.warmup + k)
-        acc["total_bytes"] += st["total_bytes"]; acc["inner"] += st["inner_iters_total"]; acc["outer"] += st["outer_iters_total"]
-        acc["ms_device"] += st["ms_device"]
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # Roofline leg: the SAME K steps again with every tvl1_iter launch bracketed by a HIP event pair on the engine's
-    # stream.  Kept out of the timed region above because ~1200 event records per step cost ~8% of a step.
-    if not a.no_profile:
-        eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include the other lane's kernels
-        eng.set_profile(1)
-        for k in range(a.steps):
-            st = step(a.warmup + a.steps + k)
-            acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
-        drain()
-        torch.cuda.synchronize(dev)
-        eng.set_profile(0)
-        eng.set_tuning("lanes", a.lanes)
-
-    out = None
+    out = run_leg(a, a.algo, B, a.steps, a.warmup, I0s, I1s, torch, dist, dev, rank, world, local_rank,
+                  live_pmc=live.get(a.algo), cpu_sample=a.cpu_sample)
+    if want_df:
+        df = run_leg(a, "deepflow", DB, a.deepflow_steps, 1, I0s[:DB], I1s[:DB], torch, dist, dev, rank, world, local_rank,
+                     live_pmc=live.get("deepflow"), cpu_sample=2)
+        if rank == 0:
+            df["why"] = "OF_algo='deepflow' is what the reference's CLI runs (calculate_optical_flow.py:735-739); BASELINE configs[3]"
+            out["deepflow"] = df
     if rank == 0:
-        pairs = world * B * a.steps
-        launches = max(acc["iter_launches"], 1)
-        avg_launch_ms = acc["iter_ms"] / launches if acc["iter_ms"] > 0 else None
-        bytes_per_launch = acc["iter_bytes"] / launches
-        achieved = (bytes_per_launch / 1e9) / (avg_launch_ms / 1e3) if avg_launch_ms else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    traffic = json.load(f).get("tvl1_iter_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
-        if a.algo == "TVL1":
-            ROOF = {"bound": "hbm", "kernel": "k_iter2_rows (tvl1_iter, two inner iterations per launch)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
-                         "launches": acc["iter_launches"], "bytes_per_px_iteration": 60,
-                         "note": "achieved = executed pair-iterations x px x 60 B (the single-iteration kernel's compulsory traffic) / summed launch "
-                                 "time; the launched kernel fuses two iterations, so its real HBM traffic (`traffic`, PMC) is about half of that "
-                                 "and the kernel is bound by fp32/fp64 VALU issue (see DESIGN.md section 4)",
-                         "measured_on": f"{a.steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
-        else:
-            ROOF = {"bound": "hbm", "kernel": "k_df_sor_fused (red-black SOR, 4 sweeps per launch on 64x32 LDS tiles, 1024-thread blocks; whole levels up to 96x96 in one launch; dominant)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms, "launches": acc["iter_launches"],
-                    "bytes_per_px_sweep": 40,
-                    "note": "achieved = executed pixel-sweeps x 40 B (compulsory traffic of ONE red-black sweep: du, dv, weight, A11, A12, "
-                            "A22, b1, b2 read, du, dv written) / summed launch time, one HIP event pair per launch, single lane; the kernel "
-                            "fuses 4 sweeps per launch on LDS tiles (25 on levels that fit one block), so about a quarter of that goes through HBM and the kernel is bound by "
-                            "LDS latency and the two IEEE divisions per update"}
-        out = {
-            "metric": "frame-pairs/sec @512x512 " + ("DualTVL1" if a.algo == "TVL1" else "DeepFlow"), "value": pairs / dt, "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
-                                   "configs[2] per-GPU shard), speckle-warp v1 seeds rank*B..; "
-                                   + ("DualTVL1 all defaults, lambda 0.15, 5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; "
-                                      if a.algo == "TVL1" else
-                                      "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
-                                   + "inputs resident in HBM; "
-                                   + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
-                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}", "lanes_per_gpu": a.lanes},
-            "roofline": ROOF,
-            "executed_inner_iterations_per_pair": acc["inner"] / (B * a.steps),
-            "executed_outer_iterations_per_pair": acc["outer"] / (B * a.steps),
-            "whole_solve_algorithmic_GBps": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
-        }
-        # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
-        lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1, algo=a.algo)
-        for k, v in tuning:
-            lat_eng.set_tuning(k, int(v))
-        f1 = torch.empty((1, H, W, 2), dtype=torch.float32, device=dev)
-        for _ in range(3):
-            lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
-        torch.cuda.synchronize(dev)
-        tl = time.perf_counter()
-        for _ in range(10):
-            lat_eng.calc_pairs_device(p0, p1, 1, H, W, f1.data_ptr())
-        torch.cuda.synchronize(dev)
-        out["latency_ms_single_pair"] = (time.perf_counter() - tl) / 10 * 1e3
-        lat_eng.close()
-        # the same step through the host-pointer entry point (PCIe in and out included) -- reported beside, never as `value`
-        eng.calc_pairs(I0s, I1s)                   # result arrays come from the engine's pinned pool: this call fills it
-        tp = time.perf_counter()
-        eng.calc_pairs(I0s, I1s)
-        out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
-        if world == 1 and not a.no_cpu_baseline:
-            n = min(a.cpu_sample, B)
-            cb, ref = cpu_baseline(I0s, I1s, n, a.algo)
-            out["cpu_baseline"] = cb
-            from oracle import oracle as O
-            O.set_num_threads(1)
-            t1 = time.perf_counter()
-            (O.tvl1_calc if a.algo == "TVL1" else O.deepflow_calc)(I0s[0], I1s[0])
-            out["cpu_baseline_1_thread_pairs_per_s"] = 1.0 / (time.perf_counter() - t1)
-            O.set_num_threads(O.effective_cpus())
-            last = a.warmup + a.steps - 1 + (0 if a.no_profile else a.steps)
-            got = flows[last & 1][:n].cpu().numpy()
-            diff = max(float(np.abs(got[i] - ref[i]).max()) for i in range(n))
-            out["parity_vs_oracle_max_abs_diff_on_cpu_sample"] = diff
-    eng.close()
+        out["kernel_source_fingerprint"] = kernel_source_fingerprint()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
