@@ -169,7 +169,8 @@ int tf_device_count(void);
 /* implementation knobs for experiments: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips, 2 = row strips
  * with two iterations per launch), "min_rows_work" (rows*pairs below which tiles are used),
  * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
- * stop reports). Results never change. */
+ * stop reports), "sched" (1 = free-running pair scheduler for batches of >= "sched_min_pairs" pairs, 0 = lock-step
+ * stages), "lanes" (independent engine lanes a batch is split over). Results never change. */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);
@@ -191,7 +192,9 @@ int tf_wase_compensate(tf_handle* h, float* flows, int n_flows, const uint8_t* b
 int tf_wase_compensate_device(tf_handle* h, float* flows, int n_flows, const uint8_t* bkgd, int n_frames, int H, int W, float scale,
                               float* background_out);
 /* per-launch record of the last solve run with tf_set_profile(h, 1): tvl1_iter launches in issue order (single lane);
- * returns the number of records, fills at most max_n */
+ * returns the number of records, fills at most max_n.  Lock-step driver: (level, warp, first iteration) of the launch.
+ * Scheduler driver (pairs of every level mixed in one launch): level = -1, warp = thousands of pixel-iterations the
+ * launch executed, it = super-step index. */
 int tf_dbg_launch_profile(tf_handle* h, int* level, int* warp, int* it, float* ms, int max_n);
 /* strip sizing rule of the tvl1_iter kernel (host arithmetic only): rows per strip R (multiple of RY) and strip count S
  * for n_active pairs still iterating on a device with `slots` resident blocks */

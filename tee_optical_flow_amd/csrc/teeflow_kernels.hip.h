@@ -137,20 +137,14 @@ struct WarpArgs {
     Geom g;
 };
 
-__global__ __launch_bounds__(256) void k_warp(WarpArgs a)
+// one output pixel of the warp stage; every pointer is already offset to the pair's plane (I0 / I1: to its frames)
+__device__ __forceinline__ void warp_px(const float* stab, const float* __restrict__ I0, const float* __restrict__ I1,
+                                        const float* __restrict__ gu1, const float* __restrict__ gu2,
+                                        float* __restrict__ owx, float* __restrict__ owy, float* __restrict__ orho,
+                                        int W, int H, int pitch, int x, int y)
 {
-    __shared__ float stab[128];
-    if (threadIdx.x < 128) stab[threadIdx.x] = a.tab[threadIdx.x];
-    __syncthreads();
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
-    if (x >= W || y >= H) return;
-    const int uc = a.ctl[b].ubase & 1;
-    const size_t po = (size_t)b * a.g.splane, idx = (size_t)y * pitch + x;
-    const float u1 = a.sb.u1[uc][po + idx], u2 = a.sb.u2[uc][po + idx];
-    const float* __restrict__ I0 = a.pyr + (size_t)(a.off0 + b) * a.g.plane;
-    const float* __restrict__ I1 = a.pyr + (size_t)(a.off1 + b) * a.g.plane;
+    const size_t idx = (size_t)y * pitch + x;
+    const float u1 = gu1[idx], u2 = gu2[idx];
     const float mx = (float)x + u1, my = (float)y + u2;
     const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
     const float* wxp = stab + (sx & 31) * 4;
@@ -212,9 +206,24 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs a)
             }
         }
     }
-    a.wx[po + idx] = vX;
-    a.wy[po + idx] = vY;
-    a.rho[po + idx] = ((vI - vX * u1) - vY * u2) - I0[idx];
+    owx[idx] = vX;
+    owy[idx] = vY;
+    orho[idx] = ((vI - vX * u1) - vY * u2) - I0[idx];
+}
+
+__global__ __launch_bounds__(256) void k_warp(WarpArgs a)
+{
+    __shared__ float stab[128];
+    if (threadIdx.x < 128) stab[threadIdx.x] = a.tab[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    if (x >= W || y >= H) return;
+    const int uc = a.ctl[b].ubase & 1;
+    const size_t po = (size_t)b * a.g.splane;
+    warp_px(stab, a.pyr + (size_t)(a.off0 + b) * a.g.plane, a.pyr + (size_t)(a.off1 + b) * a.g.plane, a.sb.u1[uc] + po, a.sb.u2[uc] + po,
+            a.wx + po, a.wy + po, a.rho + po, W, H, pitch, x, y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -989,21 +998,26 @@ __device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
 
 // `slots` > 0: grid = (max work items, 1, 1) and every block finds its (pair, strip) among the pairs that still iterate;
 // `slots` == 0: grid = (strips, 1, pairs) with the fixed strip length R.
+// What one block of the two-iteration row march needs to know: which pair and strip, the strip length, the block shape
+// and the pair's mode.  The lock-step launch derives it from launch-uniform arguments + the pair's error slots
+// (k_iter2_rows), the free-running scheduler from the pair's own state (teeflow_sched.hip.h).
+struct Iter2Blk {
+    int b, strip, R, QX, RY;
+    bool replay, pzero;
+    int uc, pc;          // ping-pong halves the block READS u / p from (it writes the other ones)
+    int it;              // first of the two iterations (error slots it, it+1)
+    u64* errb;           // the pair's error slots
+    int W, H, pitch;     // geometry of the pair's level
+    long long splane;    // floats between consecutive pairs in the state / constant buffers
+};
+
+__device__ __forceinline__ void iter2_rows_body(const IterArgs& a, const Iter2Blk& k, float* smem);
+
 __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, int RY, int slots)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IterArgs& a = A.a;
-    const int LW = QX * 4 + 4;
     u64* sred = reinterpret_cast<u64*>(smem);      // 2 x 8 x u64 = 128 B (one per wave and error sum)
-    float* U1a = smem + 32;                        // [2][RY][LW]  u1 (first iterate) plane 1 / 2
-    float* U1b = U1a + 2 * RY * LW;
-    float* U2a = U1b + 2 * RY * LW;                // [2][RY][LW]  u2 (second iterate)
-    float* U2b = U2a + 2 * RY * LW;
-    float* B12 = U2b + 2 * RY * LW;                // [RY+1][LW]   rolling rows of p1_12 / p1_22 (p0's row above is
-                                                   //              re-read from global/L2: keeps LDS at 3 blocks per CU)
-    float* B22 = B12 + (RY + 1) * LW;
-    float* B11w = B22 + (RY + 1) * LW;             // [RY][QX]     last element of each quad of p1_11 / p1_21
-    float* B21w = B11w + RY * QX;
 
     publish_active_count2(A);
     int b = blockIdx.z, strip = blockIdx.x;
@@ -1038,17 +1052,40 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
     const bool replay = mode == M_REPLAY;
     const PairCtl c = a.ctl[b];
     const int utog = replay ? A.utog_prev : a.utog, ptog = replay ? A.ptog_prev : a.ptog;
-    const bool pzero = (replay ? A.pzero_prev : a.pzero) != 0;
-    const int uc = (c.ubase ^ utog) & 1, pc = (c.pbase ^ ptog) & 1;
+    Iter2Blk blk;
+    blk.b = b; blk.strip = strip; blk.R = R; blk.QX = QX; blk.RY = RY; blk.replay = replay;
+    blk.pzero = (replay ? A.pzero_prev : a.pzero) != 0;
+    blk.uc = (c.ubase ^ utog) & 1; blk.pc = (c.pbase ^ ptog) & 1;
+    blk.it = a.it; blk.errb = errb;
+    blk.W = a.g.w; blk.H = a.g.h; blk.pitch = a.g.pitch; blk.splane = a.g.splane;
+    iter2_rows_body(a, blk, smem);
+}
+
+__device__ __forceinline__ void iter2_rows_body(const IterArgs& a, const Iter2Blk& k, float* smem)
+{
+    const int b = k.b, strip = k.strip, R = k.R, QX = k.QX, RY = k.RY, uc = k.uc, pc = k.pc;
+    const bool replay = k.replay, pzero = k.pzero;
+    u64* errb = k.errb;
+    const int LW = QX * 4 + 4;
+    u64* sred = reinterpret_cast<u64*>(smem);      // 2 x 8 x u64 = 128 B (one per wave and error sum)
+    float* U1a = smem + 32;                        // [2][RY][LW]  u1 (first iterate) plane 1 / 2
+    float* U1b = U1a + 2 * RY * LW;
+    float* U2a = U1b + 2 * RY * LW;                // [2][RY][LW]  u2 (second iterate)
+    float* U2b = U2a + 2 * RY * LW;
+    float* B12 = U2b + 2 * RY * LW;                // [RY+1][LW]   rolling rows of p1_12 / p1_22 (p0's row above is
+                                                   //              re-read from global/L2: keeps LDS at 3 blocks per CU)
+    float* B22 = B12 + (RY + 1) * LW;
+    float* B11w = B22 + (RY + 1) * LW;             // [RY][QX]     last element of each quad of p1_11 / p1_21
+    float* B21w = B11w + RY * QX;
     const int tid = threadIdx.x;
     const int ty = tid / QX, tx = tid - ty * QX;
     const bool lane_on = ty < RY;
-    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    const int W = k.W, H = k.H, pitch = k.pitch;
     const int x = tx * 4;
     const int y0 = strip * R;
     // the first primal update covers rows y0-1 .. y0+R+1; groups of RY rows start at y0-1 (R need not be a multiple of RY)
     const int ngroups = (R + 3 + RY - 1) / RY;
-    const size_t po = (size_t)b * a.g.splane;
+    const size_t po = (size_t)b * (size_t)k.splane;
     const int RB = RY + 1;
 
     const float* __restrict__ gu1 = a.sb.u1[uc] + po;
@@ -1257,8 +1294,8 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         if (tid == 0) {
             u64 ta = 0, tb = 0;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += sred[w]; tb += sred[8 + w]; }
-            atomicAdd(&errb[a.it], ta);
-            atomicAdd(&errb[a.it + 1], tb);
+            atomicAdd(&errb[k.it], ta);
+            atomicAdd(&errb[k.it + 1], tb);
         }
     }
 }
@@ -1413,6 +1450,20 @@ __global__ __launch_bounds__(256) void k_iter2_tile(Iter2Args A)
     }
 }
 
+// one 64 x 16 output tile of one flow plane: stage the tile + halo (replicate border) in LDS, then the selection network
+template <int KS>
+__device__ __forceinline__ void median_block(float (*t)[64 + 2 * (KS / 2)], const float* __restrict__ src, float* __restrict__ dst,
+                                             int x0, int y0, int W, int H, int pitch)
+{
+    constexpr int R = KS / 2, LW = 64 + 2 * R, LH = 16 + 2 * R;
+    for (int ly = threadIdx.x >> 6; ly < LH; ly += 4) {
+        const float* row = src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch;
+        for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
+    }
+    __syncthreads();
+    median_tile<KS, LW>(t, dst, x0, y0, W, H, pitch);
+}
+
 // median for the two-iterations-per-launch schedule: a pair takes part iff it is in NORMAL mode at `it`
 template <int KS>
 __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
@@ -1426,12 +1477,7 @@ __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
     const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
     float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
     const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
-    for (int ly = threadIdx.x >> 6; ly < LH; ly += 4) {
-        const float* row = src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch;
-        for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
-    }
-    __syncthreads();
-    median_tile<KS, LW>(t, dst, x0, y0, W, H, pitch);
+    median_block<KS>(t, src, dst, x0, y0, W, H, pitch);
 }
 
 // stage end for the two-iterations-per-launch schedule: a pair took part in ceil(n_it/2) launches
