@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 1
+#define TF_ABI_VERSION 2   /* 2: tf_stats grew the per-stage times ms_warp .. ms_sched */
 
 enum {
     TF_OK = 0,
@@ -77,6 +77,10 @@ typedef struct tf_stats {
     double total_bytes;                    /* algorithmic bytes of the whole solve */
     unsigned long long inner_iters_total;  /* sum over pairs/levels/warps of executed inner iterations */
     unsigned long long outer_iters_total;  /* ... of executed outer iterations (= median passes) */
+    /* summed launch durations per stage of the solve, filled like iter_ms only under tf_set_profile(h,1), single lane.
+     * Lock-step driver: ms_warp (k_warp) and ms_median (k_median2) separately.  Scheduler driver: the warp / median /
+     * upsample / output tiles of all pairs share one kernel per super-step (ms_misc) and ms_sched is the state machine. */
+    double ms_warp, ms_median, ms_misc, ms_sched;
 } tf_stats;
 
 typedef struct tf_handle tf_handle;

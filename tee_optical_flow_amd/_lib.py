@@ -42,7 +42,8 @@ class TfStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_device", C.c_double), ("ms_d2h", C.c_double),
                 ("iter_launches", C.c_ulonglong), ("iter_pair_steps", C.c_ulonglong), ("iter_ms", C.c_double),
                 ("iter_bytes", C.c_double), ("total_bytes", C.c_double), ("inner_iters_total", C.c_ulonglong),
-                ("outer_iters_total", C.c_ulonglong)]
+                ("outer_iters_total", C.c_ulonglong), ("ms_warp", C.c_double), ("ms_median", C.c_double),
+                ("ms_misc", C.c_double), ("ms_sched", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
@@ -106,7 +107,7 @@ def load():
     L.tf_dbg_iterate.argtypes = [vp] + [vp] * 9 + [i32, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)  # AttributeError here = header/library mismatch
-    if L.tf_abi_version() != 1:
+    if L.tf_abi_version() != 2:
         raise OpticalFlowCalculationError("libteeflow_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -70,7 +70,7 @@ struct tf_handle {
     float* st_flow = nullptr; size_t st_flow_bytes = 0;
     hipEvent_t ev[4] = {};
     // profiling of tvl1_iter launches
-    std::vector<ProfEv> prof_pool; size_t prof_used = 0;
+    std::deque<ProfEv> prof_pool; size_t prof_used = 0;      // deque: records keep their address while the pool grows
     // results of the last call
     std::vector<int> last_iters; int last_pairs = 0, last_nlev = 0, last_warps = 0;
     // per-call accumulators
@@ -122,13 +122,18 @@ struct tf_handle {
                                  // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
+    int small_w = 0, small_slots_pct = 100, small_ry = 0;   // experiments: levels at most small_w px wide size their strips for a
+                                                            // fraction of the resident-block slots / take small_ry rows per step
+    int mid_lo = 0, mid_hi = 0, mid_ry = 0;                 // experiments: levels with mid_lo < w <= mid_hi take mid_ry rows per step
     // free-running pair scheduler (teeflow_sched.hip.h): every pair walks through its own stages; used when the batch is
     // large enough for the row strips, the level count fits SC_MAXLEV and the frames are at most 1024 px wide
-    int sched = 1, sched_min_pairs = 24, sched_lag = 2, misc_blocks_per_cu = 8;
+    int sched = 0, sched_min_pairs = 24, sched_lag = 2, misc_blocks_per_cu = 8;
+    int sched_overlap = 1;       // k_misc_q of a super-step runs on a second stream beside k_iter2_q (they touch different pairs)
+    hipStream_t misc_stream = nullptr; hipEvent_t sc_ev[16] = {};
     PairSt* sc_st = nullptr; int* sc_cnt = nullptr; int* sc_items = nullptr; int sc_items_cap = 0;
     int* sc_mpair = nullptr; int* sc_mpref = nullptr; double* sc_work = nullptr; int sc_work_cap = 0;
     std::vector<double> sc_work_host;
-    double misc_ms = 0, sched_ms = 0;      // profiling: summed k_misc_q / k_sched launch durations of the last call
+    double misc_ms = 0, sched_ms = 0, warp_ms = 0, median_ms = 0;   // profiling: summed launch durations per stage of the last call
 };
 
 TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out);
@@ -293,9 +298,12 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
     const int qx = (g.w + 3) / 4;
     int ry = 256 / qx;
     if (ry < 1) ry = 1;
-    if (h->force_ry > 0 && qx * h->force_ry <= 512) ry = h->force_ry;
+    int forced = h->force_ry;
+    if (g.w <= h->small_w && h->small_ry > 0) forced = h->small_ry;
+    if (g.w > h->mid_lo && g.w <= h->mid_hi && h->mid_ry > 0) forced = h->mid_ry;
+    if (forced > 0 && qx * forced <= 512) ry = forced;
     *QX = qx; *RY = ry;
-    *threads = (qx * ry <= 256 && h->force_ry <= 0) ? 256 : (qx * ry + 63) / 64 * 64;   // forced shapes: no idle waves
+    *threads = (qx * ry <= 256 && forced <= 0) ? 256 : (qx * ry + 63) / 64 * 64;   // forced shapes: no idle waves
     long long n = (long long)g.h * B / ((long long)h->strip_blocks * ry);
     if (n < 2) n = 2;
     if (n > 16) n = 16;
@@ -329,6 +337,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
             }
             slots = f->second;
         }
+        if (g.w <= h->small_w && h->small_slots_pct > 0 && h->small_slots_pct < 100) slots = slots * h->small_slots_pct / 100;
         int items = 1;
         for (int n = 1; n <= B; ++n) {
             int r, sn;
@@ -374,6 +383,16 @@ void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s)
     }
 }
 
+ProfEv* prof_next(tf_handle* h)
+{
+    if (h->prof_used == h->prof_pool.size()) {
+        ProfEv pe;
+        if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) return nullptr;
+        h->prof_pool.push_back(pe);
+    }
+    return &h->prof_pool[h->prof_used++];
+}
+
 // one (level, warp) stage for pairs [0,B)
 int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 {
@@ -387,7 +406,14 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     WarpArgs wa;
     wa.pyr = h->pyr[l]; wa.off0 = off0; wa.off1 = off1; wa.sb = h->sb; wa.ctl = h->ctl; wa.tab = h->tab;
     wa.wx = h->cwx; wa.wy = h->cwy; wa.rho = h->crho; wa.g = g;
-    launch_warp(h, wa, B, s);
+    if (h->profile) {
+        ProfEv* pe = prof_next(h);
+        if (!pe) return fail(h, TF_ERR_HIP, "hipEventCreate failed");
+        pe->level = -4;
+        HIPC(h, hipEventRecord(pe->a, s));
+        launch_warp(h, wa, B, s);
+        HIPC(h, hipEventRecord(pe->b, s));
+    } else launch_warp(h, wa, B, s);
     HIPC(h, hipMemsetAsync(h->errs, 0, (size_t)B * h->errstride * sizeof(u64), s));
 
     IterArgs ia;
@@ -410,8 +436,11 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
         for (int it = 0; it <= total && !stop; it += 2) {
             if (it < total && it % inner == 0 && P.median_filtering > 1) {
                 ma.it = it; ma.utog = utog;
+                ProfEv* pm = h->profile ? prof_next(h) : nullptr;
+                if (pm) { pm->level = -5; HIPC(h, hipEventRecord(pm->a, s)); }
                 if (P.median_filtering == 5) hipLaunchKernelGGL(k_median2<5>, gm, dim3(256), 0, s, ma, total);
                 else hipLaunchKernelGGL(k_median2<3>, gm, dim3(256), 0, s, ma, total);
+                if (pm) HIPC(h, hipEventRecord(pm->b, s));
                 ++utog;
             }
             const unsigned q = h->launch_seq++;
@@ -550,16 +579,6 @@ bool sched_ok(const tf_handle* h, int B)
            B >= h->sched_min_pairs && B <= 1024 && rows_ok(h, h->lv[0], B);
 }
 
-ProfEv* prof_next(tf_handle* h)
-{
-    if (h->prof_used == h->prof_pool.size()) {
-        ProfEv pe;
-        if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) return nullptr;
-        h->prof_pool.push_back(pe);
-    }
-    return &h->prof_pool[h->prof_used++];
-}
-
 // Same contract as solve_resident.  The host only enqueues super-steps (k_sched, k_misc_q, k_iter2_q) until the device
 // reports that every pair is done; it reads those reports `sched_lag` super-steps late and never blocks the stream.
 int solve_resident_sched(tf_handle* h, const uint8_t* dframes, int F, int B, int off0, int off1, float scale, float* dflow)
@@ -620,6 +639,11 @@ int solve_resident_sched(tf_handle* h, const uint8_t* dframes, int F, int B, int
     IA.a.l_t = (float)(P.lambda * P.theta); IA.a.theta = (float)P.theta; IA.a.taut = (float)(P.tau / P.theta);
     IA.st = h->sc_st; IA.cnt = h->sc_cnt; IA.items = h->sc_items; IA.splane = h->lv[0].plane;
 
+    const bool overlap = h->sched_overlap != 0;
+    if (overlap && !h->misc_stream) {
+        HIPC(h, hipStreamCreateWithFlags(&h->misc_stream, hipStreamNonBlocking));
+        for (auto& e : h->sc_ev) HIPC(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     const int sched_threads = (B + 63) / 64 * 64;
     const int iter_grid = (slots > B ? slots : B) + B + 64 < h->sc_items_cap ? (slots > B ? slots : B) + B + 64 : h->sc_items_cap;
     const int misc_grid = h->num_cus * (h->misc_blocks_per_cu > 0 ? h->misc_blocks_per_cu : 8);
@@ -643,13 +667,24 @@ int solve_resident_sched(tf_handle* h, const uint8_t* dframes, int F, int B, int
             HIPC(h, hipEventRecord(e0->a, s));
         }
         hipLaunchKernelGGL(k_sched, dim3(1), dim3(sched_threads), 0, s, SA);
-        if (h->profile) { HIPC(h, hipEventRecord(e0->b, s)); HIPC(h, hipEventRecord(e1->a, s)); }
-        if (P.median_filtering == 5) hipLaunchKernelGGL(k_misc_q<5>, dim3(misc_grid), dim3(256), 0, s, MA);
-        else if (P.median_filtering == 3) hipLaunchKernelGGL(k_misc_q<3>, dim3(misc_grid), dim3(256), 0, s, MA);
-        else hipLaunchKernelGGL(k_misc_q<1>, dim3(misc_grid), dim3(256), 0, s, MA);
-        if (h->profile) { HIPC(h, hipEventRecord(e1->b, s)); HIPC(h, hipEventRecord(e2->a, s)); }
+        if (h->profile) HIPC(h, hipEventRecord(e0->b, s));
+        hipStream_t ms = s;
+        if (overlap) {       // fork: the tile kernel of this super-step runs beside the iteration kernel
+            ms = h->misc_stream;
+            HIPC(h, hipEventRecord(h->sc_ev[(2 * ss) & 15], s));
+            HIPC(h, hipStreamWaitEvent(ms, h->sc_ev[(2 * ss) & 15], 0));
+        }
+        if (h->profile) HIPC(h, hipEventRecord(e1->a, ms));
+        if (P.median_filtering == 5) hipLaunchKernelGGL(k_misc_q<5>, dim3(misc_grid), dim3(256), 0, ms, MA);
+        else if (P.median_filtering == 3) hipLaunchKernelGGL(k_misc_q<3>, dim3(misc_grid), dim3(256), 0, ms, MA);
+        else hipLaunchKernelGGL(k_misc_q<1>, dim3(misc_grid), dim3(256), 0, ms, MA);
+        if (h->profile) { HIPC(h, hipEventRecord(e1->b, ms)); HIPC(h, hipEventRecord(e2->a, s)); }
         hipLaunchKernelGGL(k_iter2_q, dim3(iter_grid), dim3(256), shmem, s, IA);
         if (h->profile) HIPC(h, hipEventRecord(e2->b, s));
+        if (overlap) {       // join: the next k_sched reads what both kernels wrote
+            HIPC(h, hipEventRecord(h->sc_ev[(2 * ss + 1) & 15], ms));
+            HIPC(h, hipStreamWaitEvent(s, h->sc_ev[(2 * ss + 1) & 15], 0));
+        }
         ++h->iter_launches;
         while (checked <= q) {
             int v = h->slots_host[checked % SLOT_RING];
@@ -1017,7 +1052,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
                           &st->inner_iters_total, &st->outer_iters_total);
         st->iter_pair_steps = st->inner_iters_total;
         double ims = 0;
-        h->misc_ms = h->sched_ms = 0;
+        h->misc_ms = h->sched_ms = h->warp_ms = h->median_ms = 0;
         for (size_t i = 0; i < h->prof_used; ++i) {
             float t = 0;
             ProfEv& pe = h->prof_pool[i];
@@ -1025,10 +1060,13 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
             pe.ms = t;
             if (pe.level == -2) h->sched_ms += t;
             else if (pe.level == -3) h->misc_ms += t;
+            else if (pe.level == -4) h->warp_ms += t;
+            else if (pe.level == -5) h->median_ms += t;
             else ims += t;
             if (pe.level == -1 && (size_t)pe.it < h->sc_work_host.size()) pe.work = h->sc_work_host[(size_t)pe.it];
         }
         st->iter_ms = ims;
+        st->ms_warp = h->warp_ms; st->ms_median = h->median_ms; st->ms_misc = h->misc_ms; st->ms_sched = h->sched_ms;
         st->ms_total = now_ms() - t0;
     }
     return TF_OK;
@@ -1063,7 +1101,8 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
-        t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu;
+        t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu; t->sched_overlap = h->sched_overlap;
+        t->small_w = h->small_w; t->small_slots_pct = h->small_slots_pct; t->small_ry = h->small_ry; t->mid_lo = h->mid_lo; t->mid_hi = h->mid_hi; t->mid_ry = h->mid_ry;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1089,6 +1128,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
             st->ms_d2h = std::max(st->ms_d2h, sb.ms_d2h);
             st->iter_launches += sb.iter_launches; st->iter_pair_steps += sb.iter_pair_steps; st->iter_ms += sb.iter_ms;
             st->iter_bytes += sb.iter_bytes; st->total_bytes += sb.total_bytes;
+            st->ms_warp += sb.ms_warp; st->ms_median += sb.ms_median; st->ms_misc += sb.ms_misc; st->ms_sched += sb.ms_sched;
             st->inner_iters_total += sb.inner_iters_total; st->outer_iters_total += sb.outer_iters_total;
         }
     }
@@ -1236,6 +1276,8 @@ TF_API void tf_destroy(tf_handle* h)
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& pe : h->prof_pool) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->misc_stream) (void)hipStreamDestroy(h->misc_stream);
+    for (auto& e : h->sc_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->cev) if (e) (void)hipEventDestroy(e);
     if (h->wa) (void)hipFree(h->wa);
     if (h->wcnt) (void)hipFree(h->wcnt);
@@ -1322,9 +1364,16 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
+    else if (n == "small_w") h->small_w = value;
+    else if (n == "small_slots_pct") h->small_slots_pct = value;
+    else if (n == "small_ry") h->small_ry = value;
+    else if (n == "mid_lo") h->mid_lo = value;
+    else if (n == "mid_hi") h->mid_hi = value;
+    else if (n == "mid_ry") h->mid_ry = value;
     else if (n == "sched") h->sched = value;
     else if (n == "sched_min_pairs") h->sched_min_pairs = value < 1 ? 1 : value;
     else if (n == "sched_lag") h->sched_lag = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (n == "sched_overlap") h->sched_overlap = value;
     else if (n == "misc_blocks") h->misc_blocks_per_cu = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);

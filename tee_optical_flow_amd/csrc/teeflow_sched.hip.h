@@ -123,33 +123,58 @@ __global__ __launch_bounds__(1024) void k_sched(SchedArgs A)
             }
         }
     }
-    // ---- strips of the iterating pairs: one round of `slots` blocks, shared in proportion to the pairs' pixel counts ----
+    // ---- strips of the iterating pairs ----
+    // A block's time is its number of pipeline steps (a step = RY rows of QX quads on 256 threads, whatever the level), so
+    // the launch is balanced when every block marches the same number of steps T: a strip of R rows takes
+    // ceil((R + 3) / RY) + 2 steps (3 halo rows, 2 steps of pipeline fill).  T is the smallest step count for which the
+    // strips of all iterating pairs fit one round of `slots` resident blocks (two rounds if there are more pairs than slots).
     const bool iter = on && (s.phase == PH_ITER || s.phase == PH_REPLAY);
     const SchedLevel L = A.lv[on && s.level >= 0 ? s.level : 0];
     const double px = iter ? (double)L.w * (double)L.h : 0.0;
-    double wsum = px, wwork = iter ? px * (s.phase == PH_ITER ? 2.0 : 1.0) : 0.0;
+    __shared__ double dsum[16], dwork[16];
+    __shared__ int nsum[16], lsum[16], ssum[16];
+    const int nwv = (int)((blockDim.x + 63) >> 6);
+    double rowsteps = iter ? (double)L.h / (double)L.ry : 0.0, wwork = iter ? px * (s.phase == PH_ITER ? 2.0 : 1.0) : 0.0;
     int n_iter = iter ? 1 : 0, n_live = on && s.phase != PH_DONE ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        wsum += __shfl_down(wsum, o, 64); wwork += __shfl_down(wwork, o, 64);
+        rowsteps += __shfl_down(rowsteps, o, 64); wwork += __shfl_down(wwork, o, 64);
         n_iter += __shfl_down(n_iter, o, 64); n_live += __shfl_down(n_live, o, 64);
     }
-    __shared__ double dsum[16], dwork[16];
-    __shared__ int nsum[16], lsum[16];
-    if ((threadIdx.x & 63) == 0) { dsum[threadIdx.x >> 6] = wsum; dwork[threadIdx.x >> 6] = wwork; nsum[threadIdx.x >> 6] = n_iter; lsum[threadIdx.x >> 6] = n_live; }
+    if ((threadIdx.x & 63) == 0) { dsum[threadIdx.x >> 6] = rowsteps; dwork[threadIdx.x >> 6] = wwork; nsum[threadIdx.x >> 6] = n_iter; lsum[threadIdx.x >> 6] = n_live; }
     __syncthreads();
-    double tot_px = 0.0, tot_work = 0.0; int tot_iter = 0, tot_live = 0;
-    for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) { tot_px += dsum[i]; tot_work += dwork[i]; tot_iter += nsum[i]; tot_live += lsum[i]; }
+    double tot_steps = 0.0, tot_work = 0.0; int tot_iter = 0, tot_live = 0;
+    for (int i = 0; i < nwv; ++i) { tot_steps += dsum[i]; tot_work += dwork[i]; tot_iter += nsum[i]; tot_live += lsum[i]; }
     int S = 0;
-    if (iter) {
+    if (tot_iter > 0) {                                                        // block-uniform
         const int rounds = (tot_iter + A.slots - 1) / A.slots;
-        const double per_block = tot_px / ((double)rounds * A.slots);                  // pixels a block should take
-        S = (int)(px / per_block + 1e-6);
-        if (S > L.smax) S = L.smax;
-        if (S < 1) S = 1;
-        const int R = (L.h + S - 1) / S;
-        S = (L.h + R - 1) / R;
-        s.strips = S; s.rows = R;
+        const int budget = rounds * A.slots;
+        int T = (int)(tot_steps / (double)budget) + 3;                         // lower bound: no strip can be shorter than that
+        if (T < 6) T = 6;                                                      // at least 4 useful steps per strip
+        for (int tries = 0; tries < 64; ++tries) {
+            int R = L.ry * (T - 2) - 3;
+            if (R < 1) R = 1;
+            int Sb = iter ? (L.h + R - 1) / R : 0;
+            if (Sb > L.smax && iter) Sb = L.smax;
+            int sum = Sb;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) ssum[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            int tot = 0;
+            for (int i = 0; i < nwv; ++i) tot += ssum[i];
+            S = Sb;
+            if (tot <= budget) break;
+            // too many strips: lengthen them; jump by the ratio when far off, by one step when close
+            const int Tn = 2 + (int)((double)(T - 2) * (double)tot / (double)budget);
+            T = Tn > T ? Tn : T + 1;
+        }
+        if (iter) {
+            const int R = (L.h + S - 1) / S;
+            S = (L.h + R - 1) / R;
+            s.strips = S; s.rows = R;
+        }
     }
     int n_items = 0;
     const int off = sc_block_scan(S, lds16, &n_items);

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in teeflow.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
-    assert L.tf_abi_version() == 1
+    assert L.tf_abi_version() == 2
 
 
 def test_ctypes_struct_layout_equals_c(tmp_path):
@@ -41,12 +41,12 @@ def test_ctypes_struct_layout_equals_c(tmp_path):
     src = tmp_path / "lay.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "teeflow.h"\nint main(){'
                    'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(tf_params), offsetof(tf_params, nscales), offsetof(tf_params, max_batch),'
-                   ' sizeof(tf_stats), offsetof(tf_stats, iter_ms), offsetof(tf_stats, outer_iters_total)); return 0; }\n')
+                   ' sizeof(tf_stats), offsetof(tf_stats, iter_ms), offsetof(tf_stats, ms_sched)); return 0; }\n')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     P, S = _lib.TfParams, _lib.TfStats
-    assert vals == [C.sizeof(P), P.nscales.offset, P.max_batch.offset, C.sizeof(S), S.iter_ms.offset, S.outer_iters_total.offset]
+    assert vals == [C.sizeof(P), P.nscales.offset, P.max_batch.offset, C.sizeof(S), S.iter_ms.offset, S.ms_sched.offset]
 
 
 def test_default_params_are_cv2_defaults():
