@@ -1,8 +1,8 @@
 """Configuration types crossing the flow boundary.
 
 `OpticalFlowCalculationConfig` mirrors /root/reference/optical_flow/config.py:174-188 field for field
-(defaults pinned by tests/golden/reference_host_side.json).  `EngineConfig` is this engine's own
-knob set (every cv2.DualTVL1OpticalFlow parameter plus device/batch) and never changes the old type.
+(defaults pinned by tests/golden/reference_host_side.json).  The engine's own knobs (every cv2.DualTVL1OpticalFlow
+parameter, device, batch) are DenseFlow's constructor arguments and setters and never change this type.
 """
 from dataclasses import dataclass
 
@@ -27,22 +27,3 @@ class OpticalFlowCalculationConfig:
 def default_optical_flow_config() -> OpticalFlowCalculationConfig:
     """Create default optical flow calculation configuration (reference config.py:191-193)."""
     return OpticalFlowCalculationConfig()
-
-
-@dataclass
-class EngineConfig:
-    """All DualTVL1 parameters (cv2.optflow.createOptFlow_DualTVL1 defaults) + engine placement."""
-    tau: float = 0.25
-    lambda_: float = 0.15
-    theta: float = 0.3
-    nscales: int = 5
-    warps: int = 5
-    epsilon: float = 0.01
-    inner_iterations: int = 30
-    outer_iterations: int = 10
-    scale_step: float = 0.8
-    gamma: float = 0.0
-    median_filtering: int = 5
-    use_initial_flow: bool = False
-    device_id: int = 0
-    max_batch: int = 128

@@ -1074,6 +1074,21 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
 
 // Entry used by the C ABI: optionally splits the batch over several lanes (this handle + twins with their own stream,
 // buffers and host thread): the launch gaps and thin tail launches of one lane are filled by the others.
+// Whatever went wrong, nothing of the failed call may still be in flight when the caller gets its buffers back (a D2H
+// copy into flow_out on the copy stream, kernels writing the caller's device buffer): drain every stream of the handle.
+int calc_common_guarded(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
+                        float* flow_out, bool device, tf_stats* st)
+{
+    const int rc = calc_common(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
+    if (rc != TF_OK && h) {
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+        if (h->misc_stream) (void)hipStreamSynchronize(h->misc_stream);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+
 int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
                float* flow_out, bool device, tf_stats* st)
 {
@@ -1081,7 +1096,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     int L = h->lanes;
     while (L > 1 && n_pairs / L < 16) --L;                   // a lane needs a batch worth its launches
     if (L < 2 || h->is_twin || !in0 || !flow_out || (mode == MODE_PAIRS && !in1) || H < 1 || W < 1 || h->stream != h->own_stream)
-        return calc_common(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
+        return calc_common_guarded(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
     while ((int)h->twins.size() < L - 1) {
         tf_handle* t = nullptr;
         int rc = h->P.algo == TF_ALGO_DEEPFLOW ? tf_create_deepflow(&h->DP, h->dev, &t) : tf_create(&h->P, h->dev, &t);
@@ -1108,9 +1123,9 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
         const int nb = first[k + 1] - first[k];
         float* fo = flow_out + (size_t)first[k] * fpx * 2;
-        th.emplace_back([=, &ss, &rcs] { rcs[k] = calc_common(t, mode, b0, b1, nb, H, W, scale, fo, device, &ss[k]); });
+        th.emplace_back([=, &ss, &rcs] { rcs[k] = calc_common_guarded(t, mode, b0, b1, nb, H, W, scale, fo, device, &ss[k]); });
     }
-    rcs[0] = calc_common(h, mode, in0, in1, first[1], H, W, scale, flow_out, device, &ss[0]);
+    rcs[0] = calc_common_guarded(h, mode, in0, in1, first[1], H, W, scale, flow_out, device, &ss[0]);
     for (auto& x : th) x.join();
     if (rcs[0]) return rcs[0];
     for (int k = 1; k < L; ++k)

@@ -59,14 +59,29 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
         import h5py
     except ImportError as e:  # pragma: no cover
         raise OpticalFlowError("h5py is required to write the HDF5 output (not installed in this interpreter)") from e
-    if os.path.exists(save_path):
-        os.remove(save_path)
-    with h5py.File(save_path, "w") as f:
+    # The file appears under its final name only when it is complete: an error half-way (the reference has a latent one --
+    # `attrs['frame_rate'] = None` raises in h5py when the DICOM lacks the tag, :405-407) never leaves a truncated .hdf5
+    # that the skip-if-exists rule of process_folder would then take for a finished study.
+    tmp_path = f"{save_path}.part{os.getpid()}"
+    try:
+        _write(h5py, tmp_path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config, mode, no_saliency,
+               include_waveforms, save_mask_subset)
+        os.replace(tmp_path, save_path)
+    finally:
+        if os.path.exists(tmp_path):
+            os.remove(tmp_path)
+
+
+def _write(h5py, path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config, mode, no_saliency,
+           include_waveforms, save_mask_subset):
+    nan = float("nan")
+    with h5py.File(path, "w") as f:
         create_gzip9(f, "echo", rgb2gray(nparr).astype(np.float16))
         fd = create_gzip9(f, "flow", np.asarray(flow_arr).astype(np.float16))
-        fd.attrs["frame_rate"] = metadata["frame_rate"]
+        # missing metadata: same attribute names and float64 type as a complete study, value NaN (units_converted says so)
+        fd.attrs["frame_rate"] = nan if metadata["frame_rate"] is None else metadata["frame_rate"]
         fd.attrs["nframes"] = nparr.shape[0]
-        fd.attrs["pixel_spacing"] = metadata["pixel_spacing"]
+        fd.attrs["pixel_spacing"] = nan if metadata["pixel_spacing"] is None else metadata["pixel_spacing"]
         fd.attrs["ID"] = patient_id
         fd.attrs["HR"] = heart_rate if heart_rate is not None else 0
         fd.attrs["no_saliency"] = no_saliency

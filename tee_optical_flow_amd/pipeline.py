@@ -1,5 +1,5 @@
-"""Study-level driver around the flow engine: the part of the reference's process_video() that sits directly on
-either side of the hot path.
+"""Study-level driver around the flow engine: the part of the reference's process_video() / process_folder() that sits
+directly on either side of the hot path.
 
 Reference: /root/reference/optical_flow/calculate_optical_flow.py
   :564-578  model construction          -> make_flow_model
@@ -7,8 +7,14 @@ Reference: /root/reference/optical_flow/calculate_optical_flow.py
   :627-660  calculate_optical_flow()    -> calculate_optical_flow (same signature/behaviour, incl. WASE quirks)
   :478-625  process_video()             -> process_video (same signature; `nparr=`/`metadata=` inject frames where the
                                            DICOM blob / pydicom are absent)
+  :243-290  process_folder()            -> process_folder (same signature and chunk / skip / per-file isolation rules;
+                                           studies are dealt round-robin over ranks and the gzip-9 HDF5 write of study k
+                                           runs beside the solve of study k+1)
 """
 import logging
+import os
+import traceback
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -83,7 +89,7 @@ def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conver
 def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode="A4C", bkgd_comp="none", flipLR=False,
                   no_saliency=False, OF_algo="TVL1", save_mask_subset=None, include_waveforms=False, waveform_folder=None,
                   config=None, *, nparr=None, metadata=None, patient_id="", heart_rate=0, waveforms=None, flow_model=None,
-                  mask_dict=None):
+                  mask_dict=None, _defer_save=None):
     """Same positional signature as the reference (:478-483).  Keyword-only extras let a caller inject what the
     offline image cannot provide: `nparr` (frames instead of a DICOM), `metadata`, `mask_dict` (segmentation result),
     `flow_model`.  Returns the float32 flow array [N,H,W,2] that was written."""
@@ -113,7 +119,11 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
             from .masks import predict_movie_thres
             mask_dict = predict_movie_thres(nparr, verbose=verbose, config=config)
         elif mode in ("A4C", "RVIO_2class"):
-            raise ConfigurationError("SAM segmentation stays stock PyTorch outside this engine: pass its result as mask_dict=")
+            if segmentor_model is None:
+                raise ConfigurationError(f"mode={mode} needs segmentor_model (a module with image_encoder / prompt_encoder / "
+                                         "mask_decoder, reference :47-88) or a precomputed mask_dict=")
+            from .masks import predict_movie
+            mask_dict = predict_movie(nparr, segmentor_model, mode=mode, verbose=verbose, config=config)   # reference :549-550
         else:
             raise ConfigurationError(f"Input for mode must be [A4C, otsu, RVIO_2class], not {mode}.")
     own = flow_model is None
@@ -127,7 +137,140 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
         if own:
             model.close()
     if save_path is not None:
-        from .hdf5_out import save_optical_flow_to_hdf5
-        save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, waveforms or {}, patient_id, heart_rate,
-                                  config, mode, no_saliency, include_waveforms and bool(waveforms), save_mask_subset)
+        job = (save_path, flow_arr, nparr, mask_dict, metadata, waveforms or {}, patient_id, heart_rate,
+               config, mode, no_saliency, include_waveforms and bool(waveforms), save_mask_subset)
+        if _defer_save is not None:
+            _defer_save(job)                      # process_folder: the writer thread takes it while the next study is solved
+        else:
+            from .hdf5_out import save_optical_flow_to_hdf5
+            save_optical_flow_to_hdf5(*job)
     return flow_arr
+
+
+def read_study(path):
+    """Frames + metadata of one study file.  `.dcm` needs pydicom (absent in this image -> DICOMReadError, as the
+    reference's _read_dicom_file failure, :520-522); `.npy` (uint8 [N,H,W] or [N,H,W,3]) and `.npz` (key `nparr`, optional
+    `pixel_spacing`, `frame_rate`, `patient_id`, `heart_rate`) are the injection formats of the offline image."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        return np.load(path, allow_pickle=False), None, "", 0
+    if ext == ".npz":
+        z = np.load(path, allow_pickle=False)
+        md = {"pixel_spacing": float(z["pixel_spacing"]) if "pixel_spacing" in z else None,
+              "frame_rate": float(z["frame_rate"]) if "frame_rate" in z else None, "R_wave_data_present": False, "R_times": None}
+        return z["nparr"], md, str(z["patient_id"]) if "patient_id" in z else "", int(z["heart_rate"]) if "heart_rate" in z else 0
+    try:
+        import pydicom
+    except ImportError as e:
+        raise DICOMReadError(f"Failed to read DICOM file: {path} (pydicom is not installed)") from e
+    ds = pydicom.dcmread(path)
+    arr = ds.pixel_array
+    md = {"pixel_spacing": None, "frame_rate": None, "R_wave_data_present": False, "R_times": None}
+    try:
+        md["pixel_spacing"] = float(ds.SequenceOfUltrasoundRegions[0].PhysicalDeltaX)
+    except Exception:
+        pass
+    for tag, f in (("CineRate", lambda v: float(v)), ("FrameTime", lambda v: 1000.0 / float(v))):
+        if md["frame_rate"] is None and hasattr(ds, tag):
+            md["frame_rate"] = f(getattr(ds, tag))
+    return arr, md, str(getattr(ds, "PatientID", "")), int(getattr(ds, "HeartRate", 0) or 0)
+
+
+def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, chunk_index=0, mode="RVIO_2class", bkgd_comp="none",
+                   flipLR=False, verbose=True, recalculate=False, no_saliency=True, OF_algo="TVL1", save_mask_subset=None,
+                   include_waveforms=False, waveform_folder=None, pixel_spacing=None, frame_rate=None, process_subset=False,
+                   file_subset_list=(), *, rank=0, world=1, extensions=("dcm",), reader=read_study, flow_model=None, config=None,
+                   device_id=0):
+    """Drop-in for the reference's process_folder (:243-290), same positional signature and the same rules:
+      * the folder listing is cut into `nchunks` slices of len // nchunks files, this call takes slice `chunk_index`
+        (the remainder files are dropped, as the reference does -- SURVEY.md Appendix C.8);
+      * a study whose `<name>.hdf5` exists is skipped unless `recalculate`;
+      * every study runs inside its own try/except: a failure is logged, recorded and the walk goes on (:276-284);
+      * files with another extension are skipped with a warning (reference: 'dcm' only; `extensions` widens that to the
+        .npy/.npz injection formats);
+      * like the reference, `pixel_spacing` / `frame_rate` are accepted and ignored, and `config` is not forwarded unless given.
+    Beyond the reference: the slice is dealt round-robin over `world` ranks (one process per GPU, rank r takes files
+    r, r+world, ...: no exchange is needed, studies are independent), one flow model serves all studies of the call, and
+    a writer thread deflates/writes study k while study k+1 is being solved.  Returns the list of (filename, error string)."""
+    os.makedirs(save_folder, exist_ok=True)
+    file_list = sorted(os.listdir(dcm_folder))                      # os.listdir order is arbitrary; sorted = same slices on every rank
+    errors = []
+    if process_subset:
+        if len(file_subset_list) == 0:
+            logger.error("ERROR! File subset list is empty!")
+            return errors
+        file_list = [f for f in file_list if f in file_subset_list]
+    if include_waveforms and waveform_folder is None:
+        logger.error("ERROR if include_waveform is selected, must define waveform_folder!")
+        return errors
+    split = len(file_list) // nchunks
+    mine = file_list[chunk_index * split:(chunk_index + 1) * split][rank::world]
+    own = flow_model is None
+    model = None
+    writer = ThreadPoolExecutor(1)
+    pending = []
+
+    def defer(job):
+        from .hdf5_out import save_optical_flow_to_hdf5
+        pending.append((job[0], writer.submit(save_optical_flow_to_hdf5, *job)))
+
+    def reap(block):
+        while pending and (block or pending[0][1].done()):
+            path, fut = pending.pop(0)
+            try:
+                fut.result()
+            except Exception as e:                                   # the writer's failure belongs to that study
+                logger.error(f"Error processing {os.path.basename(path)}: {e}")
+                errors.append((os.path.basename(path), f"{type(e).__name__}: {e}"))
+
+    try:
+        for filename in mine:
+            stem, ext = os.path.splitext(filename)
+            save_path = os.path.join(save_folder, stem + ".hdf5")
+            if os.path.exists(save_path) and not recalculate:
+                if verbose:
+                    logger.debug(f"File {save_path} exists! Skipping file {filename}")
+                continue
+            if ext.lower().lstrip(".") not in extensions:
+                logger.warning(f"File extension must be one of {extensions}, found {ext}, skipping")
+                continue
+            if verbose:
+                logger.info(f"Processing file: {filename}...")
+            try:
+                nparr, md, pid, hr = reader(os.path.join(dcm_folder, filename))
+                if model is None:
+                    model = flow_model if flow_model is not None else make_flow_model(OF_algo, config, device_id)
+                waveforms = None
+                if include_waveforms:
+                    waveforms = _load_waveforms(waveform_folder, stem)
+                process_video(os.path.join(dcm_folder, filename), save_path, segmentor_model, verbose=verbose, mode=mode,
+                              bkgd_comp=bkgd_comp, flipLR=flipLR, no_saliency=no_saliency, OF_algo=OF_algo,
+                              save_mask_subset=save_mask_subset, include_waveforms=include_waveforms, waveform_folder=waveform_folder,
+                              config=config, nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, waveforms=waveforms,
+                              flow_model=model, _defer_save=defer)
+            except Exception as e:
+                logger.error(f"Error processing {filename}: {e}")
+                if verbose:
+                    traceback.print_exc()
+                errors.append((filename, f"{type(e).__name__}: {e}"))
+            reap(block=False)
+        reap(block=True)
+    finally:
+        writer.shutdown(wait=True)
+        if own and model is not None:
+            model.close()
+    return errors
+
+
+def _load_waveforms(folder, stem):
+    """`<stem>_{II,ART,ABP,PAP,CVP}.npy` as (exists, array) pairs; validation thresholds stay with the reference's
+    waveform_loader (out of scope here) -- present files are passed through."""
+    out = {}
+    for key, names in (("ecg", ("II",)), ("art", ("ART", "ABP")), ("pap", ("PAP",)), ("cvp", ("CVP",))):
+        out[key] = (False, None)
+        for n in names:
+            p = os.path.join(folder, f"{stem}_{n}.npy")
+            if os.path.exists(p):
+                out[key] = (True, np.load(p, allow_pickle=False))
+                break
+    return out
