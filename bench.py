@@ -236,12 +236,35 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     # all-gather that read it has really finished.
     p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
     pending = [None, None]
+    # The exchange is the library's own: tf_allgather_flows = ncclAllGather on librccl, issued on the engine's communication
+    # stream (include/teeflow.h); torch.distributed only carries the 128-byte communicator id.  If RCCL cannot be set up
+    # that way (or on the gloo rehearsal backend) the step falls back to torch's all_gather_into_tensor and says so.
+    collective = "none (single GPU)"
+    lib_comm = False
+    if world > 1:
+        collective = "torch.distributed.all_gather_into_tensor"
+        if a.backend == "nccl" and not a.torch_collective:
+            try:
+                from tee_optical_flow_amd.distributed import init_engine_comm, torch_id_exchange
+                init_engine_comm(eng, rank, world, torch_id_exchange())
+                lib_comm = True
+                collective = "tf_allgather_flows: ncclAllGather issued by the library on its own stream (librccl over xGMI)"
+            except Exception as e:                       # keep the N>1 run alive; the line records which path ran
+                collective += f" (library communicator unavailable: {type(e).__name__}: {e})"
+        ok = torch.tensor([1 if lib_comm else 0], device=gdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank must take the same path
+        if lib_comm and int(ok.item()) == 0:
+            lib_comm = False
+            collective = "torch.distributed.all_gather_into_tensor (another rank could not join the library communicator)"
 
     def retire(buf):
         if pending[buf] is not None:
-            pending[buf].wait()
-            if dev.type == "cuda":
-                torch.cuda.current_stream(dev).synchronize()
+            if lib_comm:
+                eng.comm_wait(pending[buf])              # host-blocking: the buffer is free for the next solve
+            else:
+                pending[buf].wait()
+                if dev.type == "cuda":
+                    torch.cuda.current_stream(dev).synchronize()
             pending[buf] = None
 
     def step(k):
@@ -249,8 +272,11 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         retire(buf)
         st = eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
         if world > 1:
-            src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
-            pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
+            if lib_comm:
+                pending[buf] = eng.allgather(flows[buf].data_ptr(), flows[buf].numel(), gathered[buf].data_ptr())
+            else:
+                src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
+                pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
         return st
 
     def drain():
@@ -407,6 +433,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             out["executed_outer_iterations_per_pair"] = acc["outer"] / (B * steps)
             out["data_dependence_note"] = ("pairs/s depends on how early the synthetic pairs converge (executed inner iterations per pair above, of a "
                                            "possible 7500); px_iterations_per_s does not")
+        out["collective"] = collective
         if gather_ok is not None:
             out["allgather_checksums_match"] = gather_ok
         # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
@@ -471,6 +498,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--torch-collective", action="store_true", help="N>1: all-gather through torch.distributed instead of the library's tf_allgather_flows")
     ap.add_argument("--tuning", default="", help="experiments only: engine knobs as name=value,... (tf_set_tuning); empty = shipped defaults")
     ap.add_argument("--clock-ghz", type=float, default=2.4, help="shader clock assumed for the cycles-per-instruction figure (max clock; DESIGN.md notes 2.32 held under load)")
     a = ap.parse_args()

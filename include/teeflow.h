@@ -159,6 +159,27 @@ int tf_radlong_project(tf_handle* h, const float* flow, const double* centroids,
 int tf_radlong_hist(tf_handle* h, int which, const double* edges, int nbins, long long* freq_out);
 int tf_radlong_select(tf_handle* h, int which, const long long* ranks, double* values_out);
 
+/* ---- multi-GPU: the single exchange step of the path.  The reference's loop is sequential
+ *      (calculate_optical_flow.py:584-597); here pairs shard over the GPUs of a node with no data-path traffic during the
+ *      solve, and ONE RCCL all-gather of the (u,v) fields over xGMI assembles the result on every rank.  librccl is loaded
+ *      on first use.  Two ways to form the communicator:
+ *        one process per GPU : rank 0 calls tf_comm_unique_id, the launcher hands the 128 bytes to every rank (any
+ *                              channel: a file, MPI, torch.distributed's store), each rank calls tf_comm_init_rank;
+ *        one process, n GPUs : tf_comm_init_all on n handles created on n different devices (ncclCommInitAll).
+ *      tf_allgather_flows enqueues this rank's contribution (count floats, device pointers; recv holds nranks*count)
+ *      on the handle's communication stream behind the work already queued on its solve stream and returns at once with
+ *      a ticket; tf_comm_wait(h, ticket) blocks the host until that all-gather is done (ticket < 0: all of them), which
+ *      is what must happen before d_send / d_recv are reused -- so the exchange of step k overlaps the solve of step k+1.
+ *      tf_allgather_flows_all is the single-process form: grouped calls for all n ranks, returns when all are done. */
+#define TF_COMM_ID_BYTES 128
+int tf_comm_unique_id(unsigned char* id /* [TF_COMM_ID_BYTES] */);
+int tf_comm_init_rank(tf_handle* h, int nranks, int rank, const unsigned char* id);
+int tf_comm_init_all(tf_handle** handles, int n);
+int tf_allgather_flows(tf_handle* h, const float* d_send, size_t count_floats, float* d_recv, int* ticket);
+int tf_allgather_flows_all(tf_handle** handles, int n, const float* const* d_send, size_t count_floats, float* const* d_recv);
+int tf_comm_wait(tf_handle* h, int ticket);
+int tf_comm_destroy(tf_handle* h);
+
 /* Executed iteration counts of the last call: int32 [n_pairs][nscales_used][warps][2] = (inner, outer).
  * Returns the number of ints written (<= capacity) through *written. */
 int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* written);

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEEFLOW_LIB", os.path.join(_HERE, "libteeflow_hip.so"))   # override only for A/B experiments
 
 TF_OK = 0
+COMM_ID_BYTES = 128          # TF_COMM_ID_BYTES
 PARAM_KEYS = {
     "tau": 0, "lambda": 1, "theta": 2, "nscales": 3, "warps": 4, "epsilon": 5, "inner_iterations": 6,
     "outer_iterations": 7, "scale_step": 8, "gamma": 9, "median_filtering": 10, "use_initial_flow": 11,
@@ -21,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "tf_calc_pairs_device", "tf_calc_seq_device", "tf_condition_frames", "tf_calc_seq_rgb", "tf_radlong_project", "tf_radlong_hist", "tf_radlong_select", "tf_get_iters", "tf_last_error",
     "tf_set_tuning", "tf_default_deepflow_params", "tf_create_deepflow", "tf_dbg_df_refine", "tf_dbg_df_blur", "tf_dbg_launch_profile", "tf_dbg_strip_rule", "tf_wase_compensate", "tf_wase_compensate_device", "tf_host_alloc", "tf_host_free",
     "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
+    "tf_comm_unique_id", "tf_comm_init_rank", "tf_comm_init_all", "tf_allgather_flows", "tf_allgather_flows_all", "tf_comm_wait", "tf_comm_destroy",
 ]
 
 
@@ -105,6 +107,13 @@ def load():
     L.tf_dbg_warp.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.tf_dbg_median.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tf_dbg_iterate.argtypes = [vp] + [vp] * 9 + [i32, i32, i32, i32, vp]
+    L.tf_comm_unique_id.argtypes = [vp]
+    L.tf_comm_init_rank.argtypes = [vp, i32, i32, vp]
+    L.tf_comm_init_all.argtypes = [C.POINTER(vp), i32]
+    L.tf_allgather_flows.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(i32)]
+    L.tf_allgather_flows_all.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), C.c_size_t, C.POINTER(vp)]
+    L.tf_comm_wait.argtypes = [vp, i32]
+    L.tf_comm_destroy.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)  # AttributeError here = header/library mismatch
     if L.tf_abi_version() != 2:

@@ -16,6 +16,8 @@
 #include "teeflow_analysis.hip.h"
 #include "teeflow_wase.hip.h"
 #include "../../include/teeflow.h"
+#include <rccl/rccl.h>      // types and prototypes only: librccl is loaded with dlopen when a communicator is first asked for
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -133,12 +135,16 @@ struct tf_handle {
     PairSt* sc_st = nullptr; int* sc_cnt = nullptr; int* sc_items = nullptr; int sc_items_cap = 0;
     int* sc_mpair = nullptr; int* sc_mpref = nullptr; double* sc_work = nullptr; int sc_work_cap = 0;
     std::vector<double> sc_work_host;
+    // RCCL: one communicator rank per handle, its own stream, a small ring of completion events
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 0;
+    hipStream_t comm_stream = nullptr; hipEvent_t comm_ev[8] = {}; hipEvent_t comm_ready = nullptr; unsigned comm_tickets = 0;
     double misc_ms = 0, sched_ms = 0, warp_ms = 0, median_ms = 0;   // profiling: summed launch durations per stage of the last call
 };
 
 TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out);
 TF_API int tf_create_deepflow(const tf_deepflow_params* p, int device_id, tf_handle** out);
 TF_API const char* tf_last_error(tf_handle* h);
+TF_API int tf_comm_destroy(tf_handle* h);
 
 namespace {
 
@@ -1293,6 +1299,7 @@ TF_API void tf_destroy(tf_handle* h)
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->misc_stream) (void)hipStreamDestroy(h->misc_stream);
     for (auto& e : h->sc_ev) if (e) (void)hipEventDestroy(e);
+    (void)tf_comm_destroy(h);
     for (auto& e : h->cev) if (e) (void)hipEventDestroy(e);
     if (h->wa) (void)hipFree(h->wa);
     if (h->wcnt) (void)hipFree(h->wcnt);
@@ -1719,6 +1726,176 @@ TF_API int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* wr
     const size_t n = h->last_iters.size() < capacity_ints ? h->last_iters.size() : capacity_ints;
     memcpy(out, h->last_iters.data(), n * sizeof(int));
     if (written) *written = n;
+    return TF_OK;
+}
+
+// ---- multi-GPU: the ONE exchange step of the path -------------------------------------------
+// Frame pairs shard over GPUs with no data-path traffic during the solve; at the end every rank contributes its (u,v)
+// fields to a single RCCL all-gather over xGMI.  librccl is loaded on first use (dlopen), so single-GPU users never pay
+// for it and the library loads where RCCL is absent.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+Rccl* rccl()
+{
+    static Rccl R;
+    if (R.lib || !R.err.empty()) return &R;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);        // an RCCL the process already holds (torch's) is reused by SONAME
+        if (R.lib) break;
+    }
+    if (!R.lib) { R.err = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return &R; }
+    bool ok = true;
+    auto sym = [&](auto& fn, const char* n) { fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(R.lib, n)); ok = ok && fn; };
+    sym(R.GetUniqueId, "ncclGetUniqueId"); sym(R.CommInitRank, "ncclCommInitRank"); sym(R.CommInitAll, "ncclCommInitAll");
+    sym(R.AllGather, "ncclAllGather"); sym(R.GroupStart, "ncclGroupStart"); sym(R.GroupEnd, "ncclGroupEnd");
+    sym(R.CommDestroy, "ncclCommDestroy"); sym(R.GetErrorString, "ncclGetErrorString");
+    if (!ok) { R.err = "librccl lacks an expected ncclXxx symbol"; dlclose(R.lib); R.lib = nullptr; }
+    return &R;
+}
+#define NCCLC(h, call)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r_ = (call);                                                                               \
+        if (r_ != ncclSuccess) return fail(h, TF_ERR_HIP, "%s failed: %s", #call, rccl()->GetErrorString(r_));  \
+    } while (0)
+
+int comm_streams(tf_handle* h)
+{
+    if (!h->comm_stream) {
+        HIPC(h, hipSetDevice(h->dev));
+        HIPC(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        for (auto& e : h->comm_ev) HIPC(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPC(h, hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
+    }
+    return TF_OK;
+}
+}  // namespace
+
+TF_API int tf_comm_unique_id(unsigned char* id)
+{
+    if (!id) return TF_ERR_INVALID_ARG;
+    Rccl* R = rccl();
+    if (!R->lib) return fail(nullptr, TF_ERR_UNSUPPORTED, "%s", R->err.c_str());
+    ncclUniqueId u;
+    NCCLC(nullptr, R->GetUniqueId(&u));
+    static_assert(sizeof u == TF_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return TF_OK;
+}
+
+TF_API int tf_comm_init_rank(tf_handle* h, int nranks, int rank, const unsigned char* id)
+{
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return h ? fail(h, TF_ERR_INVALID_ARG, "tf_comm_init_rank: bad argument") : TF_ERR_INVALID_ARG;
+    Rccl* R = rccl();
+    if (!R->lib) return fail(h, TF_ERR_UNSUPPORTED, "%s", R->err.c_str());
+    if (h->comm) return fail(h, TF_ERR_INVALID_ARG, "this handle already has a communicator");
+    int rc = comm_streams(h);
+    if (rc) return rc;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    HIPC(h, hipSetDevice(h->dev));
+    NCCLC(h, R->CommInitRank(&h->comm, nranks, u, rank));
+    h->comm_rank = rank; h->comm_size = nranks;
+    return TF_OK;
+}
+
+TF_API int tf_comm_init_all(tf_handle** handles, int n)
+{
+    if (!handles || n < 1 || n > 64) return TF_ERR_INVALID_ARG;
+    Rccl* R = rccl();
+    if (!R->lib) return fail(handles[0], TF_ERR_UNSUPPORTED, "%s", R->err.c_str());
+    std::vector<int> devs((size_t)n);
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i] || handles[i]->comm) return fail(handles[0], TF_ERR_INVALID_ARG, "handle %d is null or already has a communicator", i);
+        devs[i] = handles[i]->dev;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i]) return fail(handles[0], TF_ERR_INVALID_ARG, "handles %d and %d sit on the same device %d", j, i, devs[i]);
+        int rc = comm_streams(handles[i]);
+        if (rc) return rc;
+    }
+    NCCLC(handles[0], R->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) { handles[i]->comm = comms[i]; handles[i]->comm_rank = i; handles[i]->comm_size = n; }
+    return TF_OK;
+}
+
+namespace {
+// enqueue this rank's part of the all-gather behind everything the handle's solve stream holds; *ticket names the event
+int enqueue_allgather(tf_handle* h, const float* d_send, size_t count, float* d_recv, int* ticket)
+{
+    Rccl* R = rccl();
+    HIPC(h, hipEventRecord(h->comm_ready, h->stream));
+    HIPC(h, hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
+    NCCLC(h, R->AllGather(d_send, d_recv, count, ncclFloat, h->comm, h->comm_stream));
+    const unsigned t = h->comm_tickets++;
+    HIPC(h, hipEventRecord(h->comm_ev[t % 8], h->comm_stream));
+    if (ticket) *ticket = (int)t;
+    return TF_OK;
+}
+}  // namespace
+
+TF_API int tf_allgather_flows(tf_handle* h, const float* d_send, size_t count_floats, float* d_recv, int* ticket)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->comm) return fail(h, TF_ERR_INVALID_ARG, "tf_allgather_flows needs tf_comm_init_rank / tf_comm_init_all first");
+    if (!d_send || !d_recv || count_floats == 0) return fail(h, TF_ERR_INVALID_ARG, "tf_allgather_flows: bad argument");
+    HIPC(h, hipSetDevice(h->dev));
+    return enqueue_allgather(h, d_send, count_floats, d_recv, ticket);
+}
+
+TF_API int tf_allgather_flows_all(tf_handle** handles, int n, const float* const* d_send, size_t count_floats, float* const* d_recv)
+{
+    if (!handles || !d_send || !d_recv || n < 1 || count_floats == 0) return TF_ERR_INVALID_ARG;
+    Rccl* R = rccl();
+    if (!R->lib) return fail(handles[0], TF_ERR_UNSUPPORTED, "%s", R->err.c_str());
+    for (int i = 0; i < n; ++i)
+        if (!handles[i] || !handles[i]->comm || handles[i]->comm_size != n) return fail(handles[0], TF_ERR_INVALID_ARG, "handle %d is not part of an %d-rank tf_comm_init_all group", i, n);
+    NCCLC(handles[0], R->GroupStart());                      // one process drives every rank: the calls must be grouped
+    int rc = TF_OK;
+    for (int i = 0; i < n && rc == TF_OK; ++i) {
+        if (hipSetDevice(handles[i]->dev) != hipSuccess) { rc = fail(handles[0], TF_ERR_HIP, "hipSetDevice(%d)", handles[i]->dev); break; }
+        rc = enqueue_allgather(handles[i], d_send[i], count_floats, d_recv[i], nullptr);
+    }
+    const ncclResult_t ge = R->GroupEnd();
+    if (rc) return rc;
+    if (ge != ncclSuccess) return fail(handles[0], TF_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString(ge));
+    for (int i = 0; i < n; ++i) {
+        if (hipSetDevice(handles[i]->dev) != hipSuccess || hipStreamSynchronize(handles[i]->comm_stream) != hipSuccess)
+            return fail(handles[0], TF_ERR_HIP, "all-gather on rank %d did not complete", i);
+    }
+    return TF_OK;
+}
+
+TF_API int tf_comm_wait(tf_handle* h, int ticket)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->comm_stream) return TF_OK;
+    HIPC(h, hipSetDevice(h->dev));
+    if (ticket < 0 || (unsigned)ticket + 8 <= h->comm_tickets) { HIPC(h, hipStreamSynchronize(h->comm_stream)); return TF_OK; }   // all / too old for the ring
+    if ((unsigned)ticket >= h->comm_tickets) return fail(h, TF_ERR_INVALID_ARG, "unknown all-gather ticket %d", ticket);
+    HIPC(h, hipEventSynchronize(h->comm_ev[(unsigned)ticket % 8]));
+    return TF_OK;
+}
+
+TF_API int tf_comm_destroy(tf_handle* h)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    if (h->comm && rccl()->lib) (void)rccl()->CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_size = 0;
+    if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+    for (auto& e : h->comm_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (h->comm_ready) { (void)hipEventDestroy(h->comm_ready); h->comm_ready = nullptr; }
     return TF_OK;
 }
 

@@ -271,6 +271,36 @@ class DenseFlow:
         return self.last_stats
 
 
+    # ---- multi-GPU exchange: RCCL all-gather issued by the library itself ------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from ncclGetUniqueId: rank 0 makes them, the launcher hands them to every rank."""
+        L = _lib.load()
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        _lib.check(L.tf_comm_unique_id(buf), None, "tf_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init_rank(self, nranks, rank, id_bytes):
+        """Join an `nranks`-rank RCCL communicator as `rank` (one process per GPU)."""
+        if len(id_bytes) != _lib.COMM_ID_BYTES:
+            raise OpticalFlowCalculationError(f"communicator id must be {_lib.COMM_ID_BYTES} bytes")
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(id_bytes)
+        _lib.check(self._L.tf_comm_init_rank(self._h, int(nranks), int(rank), buf), self._h, "tf_comm_init_rank")
+        self.has_comm = True
+
+    def allgather(self, d_send_ptr, count_floats, d_recv_ptr):
+        """Enqueue this rank's part of the all-gather of the (u,v) fields (device pointers, `count_floats` per rank);
+        returns a ticket for comm_wait.  Returns at once: the exchange runs beside whatever is solved next."""
+        t = C.c_int(-1)
+        _lib.check(self._L.tf_allgather_flows(self._h, C.c_void_p(d_send_ptr), C.c_size_t(int(count_floats)), C.c_void_p(d_recv_ptr),
+                                              C.byref(t)), self._h, "tf_allgather_flows")
+        return t.value
+
+    def comm_wait(self, ticket=-1):
+        """Block until the all-gather `ticket` (default: every one issued so far) has finished."""
+        _lib.check(self._L.tf_comm_wait(self._h, int(ticket)), self._h, "tf_comm_wait")
+
+
 def createOptFlow_DeepFlow(device_id=0, **kw):
     """Name-compatible factory for cv2.optflow.createOptFlow_DeepFlow() (reference :568)."""
     return DenseFlow(device_id=device_id, algo="deepflow", **kw)

@@ -1,11 +1,57 @@
 """Multi-GPU form of the hot path: frame pairs are independent, so the pair index range is cut
-into `world` contiguous shards (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI), each rank
-solves its shard with no data-path exchange, and ONE all-gather of the (u,v) fields assembles the result everywhere.
-The reference has no counterpart (its loop is sequential, calculate_optical_flow.py:584-597).
+into `world` contiguous shards (one process per GPU), each rank solves its shard with no data-path exchange, and ONE
+all-gather of the (u,v) fields assembles the result everywhere.  The reference has no counterpart (its loop is
+sequential, calculate_optical_flow.py:584-597).
+
+The all-gather itself is the library's: `tf_allgather_flows` (ncclAllGather on librccl over xGMI, include/teeflow.h).
+This module only cuts the shards and carries the 128-byte communicator id from rank 0 to the others over whatever channel
+the launcher has -- torch.distributed's process group when the job was started with torchrun (`torch_id_exchange`), a
+shared file otherwise (`file_id_exchange`).  On CPU tensors (gloo rehearsals, the world_size-2 tests) the gather falls
+back to torch.distributed.all_gather_into_tensor, the behaviour the library path must reproduce.
 
 Sequence mode shards with a one-frame halo: rank r needs frames [lo, hi] to produce pairs [lo, hi).
 """
+import os
+import time
+
 import numpy as np
+
+
+def torch_id_exchange(group=None):
+    """id channel over an initialised torch.distributed group: f(id_or_None) -> id on every rank."""
+    def f(payload):
+        import torch.distributed as dist
+        box = [payload]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+    return f
+
+
+def file_id_exchange(path, rank, timeout_s=120.0):
+    """id channel over a file every rank can see (no torch at all): rank 0 writes it atomically, the others poll."""
+    def f(payload):
+        if rank == 0:
+            tmp = f"{path}.{os.getpid()}"
+            with open(tmp, "wb") as fh:
+                fh.write(payload)
+            os.replace(tmp, path)
+            return payload
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"communicator id never appeared at {path}")
+            time.sleep(0.01)
+        with open(path, "rb") as fh:
+            return fh.read()
+    return f
+
+
+def init_engine_comm(engine, rank, world, exchange):
+    """Give `engine` (a DenseFlow on this rank's GPU) its rank of a `world`-rank RCCL communicator.  `exchange` is one of
+    the id channels above."""
+    ident = type(engine).comm_unique_id() if rank == 0 else None
+    ident = exchange(ident)
+    engine.comm_init_rank(world, rank, ident)
 
 
 def shard_bounds(n_items, world):
@@ -14,11 +60,17 @@ def shard_bounds(n_items, world):
     return [(min(r * s, n_items), min((r + 1) * s, n_items)) for r in range(world)], s
 
 
-def _all_gather(local, world, group):
+def _all_gather(local, world, group, engine=None):
+    """[S,...] per rank -> [world*S,...] on every rank.  Device tensors + an engine that holds a communicator: the library's
+    own ncclAllGather; otherwise torch.distributed (CPU rehearsals, tests)."""
     import torch.distributed as dist
     import torch
+    local = local.contiguous()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if engine is not None and local.is_cuda and getattr(engine, "has_comm", False):
+        engine.comm_wait(engine.allgather(local.data_ptr(), local.numel(), out.data_ptr()))
+        return out
+    dist.all_gather_into_tensor(out, local, group=group)
     return out
 
 
@@ -41,7 +93,7 @@ def sharded_sequence_flow(frames_u8, engine, rank, world, scale=1.0, group=None,
             local[:hi - lo] = torch.from_numpy(engine.calc_batch(frames_u8[lo:hi + 1], scale=scale))
     if world == 1:
         return local[:n_pairs]
-    g = _all_gather(local, world, group)
+    g = _all_gather(local, world, group, engine)
     return torch.cat([g[r * s:r * s + (b[1] - b[0])] for r, b in enumerate(bounds)])
 
 
@@ -64,5 +116,5 @@ def sharded_pairs_flow(I0s, I1s, engine, rank, world, group=None, device=None):
             local[:hi - lo] = torch.from_numpy(engine.calc_pairs(I0s[lo:hi], I1s[lo:hi]))
     if world == 1:
         return local[:B]
-    g = _all_gather(local, world, group)
+    g = _all_gather(local, world, group, engine)
     return torch.cat([g[r * s:r * s + (b[1] - b[0])] for r, b in enumerate(bounds)])

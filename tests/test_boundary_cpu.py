@@ -123,3 +123,16 @@ def test_strip_rule_covers_the_image_and_fills_one_round():
     assert (R.value, S.value) == (43, 12)
     L.tf_dbg_strip_rule(1, 512, 2, 768, C.byref(R), C.byref(S))
     assert R.value == 8 and S.value == 64                                       # capped: at least 4 steps per strip
+
+
+def test_comm_entry_points_fail_cleanly_without_a_handle():
+    """The RCCL entry points are part of the ABI; without a handle / communicator they return error
+    codes instead of touching librccl (no GPU here)."""
+    import ctypes as C
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    assert L.tf_comm_wait(None, -1) == 1 and L.tf_comm_destroy(None) == 1           # TF_ERR_INVALID_ARG
+    assert L.tf_comm_init_rank(None, 2, 0, None) == 1
+    assert L.tf_allgather_flows(None, None, 0, None, None) == 1
+    assert L.tf_comm_init_all(None, 0) == 1 and L.tf_comm_unique_id(None) == 1
+    assert _lib.COMM_ID_BYTES == 128

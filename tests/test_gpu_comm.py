@@ -1,0 +1,60 @@
+"""The library's own RCCL exchange (include/teeflow.h, tf_comm_* / tf_allgather_flows) on the one GPU a test box has: a
+1-rank communicator formed both ways (one process per GPU: unique id + init_rank; single process: init_all), the all-gather
+ticket/wait protocol, and the result equal to the rank's own flows.  N>1 needs an 8-GPU node and stays unmeasured here; the
+world_size-2 gloo tests (tests/test_distributed_cpu.py) pin the sharding logic the exchange is part of.
+
+Runs in a child process with torch imported first: the engine and torch must share one HIP runtime, and in the pytest
+process the engine's fixture has usually initialised HIP before torch is touched."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, ROOT)
+import tee_optical_flow_amd as T
+from tee_optical_flow_amd import _lib
+from tee_optical_flow_amd.distributed import init_engine_comm, file_id_exchange, sharded_pairs_flow
+from tee_optical_flow_amd.synth import speckle_pairs
+dev = torch.device("cuda", 0)
+I0s, I1s = speckle_pairs(range(4), 96, 128)
+eng = T.DenseFlow(device_id=0, max_batch=4)
+init_engine_comm(eng, 0, 1, file_id_exchange(TMP + "/id", 0))              # one process per GPU, world of 1
+out = sharded_pairs_flow(I0s, I1s, eng, 0, 1, device=dev)                   # world 1: no exchange
+ref = torch.from_numpy(np.array(eng.calc_pairs(I0s, I1s))).to(dev)
+assert torch.equal(out, ref)
+recv = [torch.zeros_like(ref) for _ in range(3)]
+tickets = [eng.allgather(ref.data_ptr(), ref.numel(), r.data_ptr()) for r in recv]      # three gathers in flight
+assert tickets == [0, 1, 2]
+eng.comm_wait(tickets[1]); eng.comm_wait(-1)
+assert all(torch.equal(r, ref) for r in recv)
+try:
+    eng.comm_wait(99)
+    raise SystemExit("an unknown ticket must be refused")
+except T.OpticalFlowCalculationError:
+    pass
+# single-process form (ncclCommInitAll + grouped calls) on one device
+eng2 = T.DenseFlow(device_id=0, max_batch=4)
+L = _lib.load()
+hs = (C.c_void_p * 1)(eng2._h)
+_lib.check(L.tf_comm_init_all(hs, 1), eng2._h, "tf_comm_init_all")
+r2 = torch.zeros_like(ref)
+snd = (C.c_void_p * 1)(ref.data_ptr()); rcv = (C.c_void_p * 1)(r2.data_ptr())
+_lib.check(L.tf_allgather_flows_all(hs, 1, snd, ref.numel(), rcv), eng2._h, "tf_allgather_flows_all")
+assert torch.equal(r2, ref)
+eng.close(); eng2.close()
+print("comm ok")
+"""
+
+
+def test_library_rccl_allgather_one_rank(tmp_path):
+    script = SCRIPT.replace("ROOT", repr(ROOT)).replace("TMP", repr(str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and "comm ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
