@@ -45,6 +45,14 @@ enum {
 
 enum { TF_ALGO_TVL1 = 0, TF_ALGO_DEEPFLOW = 1 /* handles come from tf_create_deepflow */ };
 
+/* Which OpenCV DualTVL1 the handle reproduces.  TF_VARIANT_CPU (default, the parity target): cv2.optflow's
+ * DualTVL1OpticalFlow, what calculate_optical_flow.py:577-578, 642 runs without CUDA.  TF_VARIANT_CUDA (SURVEY.md row
+ * a5): the semantics of cv2.cuda.OpticalFlowDual_TVL1 (calculate_optical_flow.py:572-575, 633-639), what the reference
+ * runs for OF_algo='TVL1' on a CUDA box -- one loop of inner*outer iterations per warp, no median filtering, the error sum
+ * looked at on odd iterations only, weight-normalised Catmull-Rom warp with clamp addressing (details and what is not
+ * modelled: oracle/tvl1_oracle.c, variant 1). */
+enum { TF_VARIANT_CPU = 0, TF_VARIANT_CUDA = 1 };
+
 /* keys for tf_set_param / tf_get_param: the 12 cv2.DualTVL1OpticalFlow setters */
 enum {
     TF_PARAM_TAU = 0, TF_PARAM_LAMBDA = 1, TF_PARAM_THETA = 2, TF_PARAM_NSCALES = 3,
@@ -59,6 +67,7 @@ typedef struct tf_params {
     int nscales, warps, inner_iterations, outer_iterations, median_filtering, use_initial_flow;
     int algo;        /* TF_ALGO_* */
     int max_batch;   /* pairs resident per sub-batch (0 = default 128) */
+    int variant;     /* TF_VARIANT_* (ABI 2) */
 } tf_params;
 
 /* Filled by every tf_calc_* call (may be NULL). Times are milliseconds (HIP events on the handle's stream). */

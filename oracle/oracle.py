@@ -22,7 +22,7 @@ class OrcParams(C.Structure):
                 ("epsilon", C.c_double), ("scale_step", C.c_double), ("gamma", C.c_double),
                 ("nscales", C.c_int), ("warps", C.c_int), ("inner_iterations", C.c_int),
                 ("outer_iterations", C.c_int), ("median_filtering", C.c_int),
-                ("use_initial_flow", C.c_int), ("err_mode", C.c_int)]
+                ("use_initial_flow", C.c_int), ("err_mode", C.c_int), ("variant", C.c_int)]
 
 
 def build(force=False):
@@ -76,6 +76,7 @@ def lib():
         L.orc_centered_gradient.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.orc_bicubic_tab.argtypes = [fp]
         L.orc_warp.argtypes = [fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.orc_warp_cuda.argtypes = [fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
         L.orc_remap_bicubic.argtypes = [fp, C.c_int, C.c_int, fp, fp, fp]
         L.orc_median_blur.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
         L.orc_iterate.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int,

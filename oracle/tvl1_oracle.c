@@ -34,6 +34,21 @@
  *       only in double-rounding corner cases (~1e-9 of calls, 1 float ulp).
  *   D3. float expressions are evaluated exactly as written, left to right, WITHOUT fused
  *       multiply-add (-ffp-contract=off).  Upstream's SIMD paths may fuse a*b+c on FMA builds.
+ *
+ * To verify first when cv2 is ever available (tests/test_cv2_probe.py): the first-row / first-column / corner forms of
+ * the divergence written here are the author's recollection of tvl1flow.cpp's divergence(); an advisor recalled a
+ * version whose parallel body covers y >= 1, x >= 1 only -- upstream then fills row 0, column 0 and the corner in three
+ * serial loops after the parallel_for_, which is what is restated here.
+ *
+ * variant 1: what a CUDA box runs for OF_algo='TVL1' in the reference --
+ * cv2.cuda.OpticalFlowDual_TVL1 (calculate_optical_flow.py:572-575, 633-639; upstream
+ * opencv_contrib/modules/cudaoptflow/src/tvl1flow.cpp + cuda/tvl1flow.cu, [UPSTREAM-FROM-MEMORY], lower confidence than
+ * the CPU variant).  The four differences SURVEY.md Appendix A lists are restated: one loop of `iterations` =
+ * inner*outer (300) per warp, no median filtering, the convergence sum evaluated only on odd iterations and only once
+ * the running `prevError` has dropped below the threshold, and a warp that samples I1, I1x, I1y with a weight-normalised
+ * Catmull-Rom (A = -0.5) bicubic over ceil(w-2)..floor(w+2) taps with clamp addressing instead of cv::remap.
+ * Not modelled: cuda::resize's own sampling rule for the pyramid / flow upsampling (the CPU forms are kept), nvcc's
+ * default FMA contraction, cuda::sum's reduction order (D1's exact sum is used).
  */
 #include <float.h>
 #include <math.h>
@@ -50,6 +65,7 @@ typedef struct {
     double tau, lambda, theta, epsilon, scale_step, gamma;
     int nscales, warps, inner_iterations, outer_iterations, median_filtering, use_initial_flow;
     int err_mode;  /* 0 = exact fixed-point sum (D1), 1 = upstream's float raster sum */
+    int variant;   /* 0 = cv2.optflow CPU DualTVL1 (the parity target), 1 = cv2.cuda.OpticalFlowDual_TVL1 semantics (row a5, below) */
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -66,7 +82,7 @@ ORC_API void orc_default_params(orc_params* p)
     /* cv2.optflow.createOptFlow_DualTVL1() defaults */
     p->tau = 0.25; p->lambda = 0.15; p->theta = 0.3; p->nscales = 5; p->warps = 5;
     p->epsilon = 0.01; p->inner_iterations = 30; p->outer_iterations = 10; p->scale_step = 0.8;
-    p->gamma = 0.0; p->median_filtering = 5; p->use_initial_flow = 0; p->err_mode = 0;
+    p->gamma = 0.0; p->median_filtering = 5; p->use_initial_flow = 0; p->err_mode = 0; p->variant = 0;
 }
 
 ORC_API int orc_num_threads(void)
@@ -228,6 +244,46 @@ ORC_API void orc_warp(const float* I0, const float* I1, const float* I1x, const 
             I1wx[i] = wx; I1wy[i] = wy;
             grad[i] = Ix2 + Iy2;
             rho_c[i] = (I1w - wx * u1[i] - wy * u2[i] - I0[i]);
+        }
+}
+
+/* cuda/tvl1flow.cu: bicubicCoeff + warpBackwardKernel (texture fetches: point sampling, clamp addressing) */
+static inline float cuda_bicubic_coeff(float x_)
+{
+    const float x = fabsf(x_);
+    if (x <= 1.0f) return x * x * (1.5f * x - 2.5f) + 1.0f;
+    else if (x < 2.0f) return x * (x * (-0.5f * x + 2.5f) - 4.0f) + 2.0f;
+    return 0.0f;
+}
+
+ORC_API void orc_warp_cuda(const float* I0, const float* I1, const float* I1x, const float* I1y,
+                           const float* u1, const float* u2, int w, int h,
+                           float* I1wx, float* I1wy, float* grad, float* rho_c)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t i = (size_t)y * w + x;
+            const float u1v = u1[i], u2v = u2[i];
+            const float wx = (float)x + u1v, wy = (float)y + u2v;
+            const int xmin = (int)ceilf(wx - 2.0f), xmax = (int)floorf(wx + 2.0f);
+            const int ymin = (int)ceilf(wy - 2.0f), ymax = (int)floorf(wy + 2.0f);
+            float sum = 0.0f, sumx = 0.0f, sumy = 0.0f, wsum = 0.0f;
+            for (int cy = ymin; cy <= ymax; ++cy)
+                for (int cx = xmin; cx <= xmax; ++cx) {
+                    const float wt = cuda_bicubic_coeff(wx - (float)cx) * cuda_bicubic_coeff(wy - (float)cy);
+                    const size_t j = (size_t)clipi(cy, 0, h) * w + clipi(cx, 0, w);
+                    sum += wt * I1[j];
+                    sumx += wt * I1x[j];
+                    sumy += wt * I1y[j];
+                    wsum += wt;
+                }
+            const float coeff = 1.0f / wsum;
+            const float I1w = sum * coeff, gx = sumx * coeff, gy = sumy * coeff;
+            const float Ix2 = gx * gx, Iy2 = gy * gy;
+            I1wx[i] = gx; I1wy[i] = gy;
+            grad[i] = Ix2 + Iy2;
+            rho_c[i] = (I1w - gx * u1v - gy * u2v - I0[i]);
         }
 }
 
@@ -418,7 +474,24 @@ static void proc_one_scale(const orc_params* P, const float* I0, const float* I1
     if (use_gamma) { memset(B->p31, 0, n * 4); memset(B->p32, 0, n * 4); }
     const float l_t = (float)(P->lambda * P->theta);
     const float taut = (float)(P->tau / P->theta);
-    for (int wi = 0; wi < P->warps; ++wi) {
+    for (int wi = 0; wi < P->warps && P->variant == 1; ++wi) {
+        /* cudaoptflow tvl1flow.cpp procOneScale: one loop, error only on odd iterations once prevError < threshold */
+        orc_warp_cuda(I0, I1, B->I1x, B->I1y, u1, u2, w, h, B->I1wx, B->I1wy, B->grad, B->rho_c);
+        const int iterations = P->inner_iterations * P->outer_iterations;
+        float error = FLT_MAX, prevError = 0.0f;
+        int n = 0;
+        for (; error > scaledEpsilon && n < iterations; ++n) {
+            const int calcError = P->epsilon > 0 && (n & 1) && prevError < scaledEpsilon;
+            const double e = iterate_once(B->I1wx, B->I1wy, B->grad, B->rho_c, u1, u2, u3, B->p11, B->p12, B->p21, B->p22,
+                                          B->p31, B->p32, B->v1, B->v2, B->v3, B->div1, B->div2, B->div3, w, h,
+                                          l_t, (float)P->theta, taut, (float)P->gamma, P->err_mode, NULL);
+            if (calcError) { error = (float)e; prevError = error; }
+            else { error = FLT_MAX; prevError -= scaledEpsilon; }
+        }
+        if (n_inner_out) n_inner_out[wi] = n;
+        if (n_outer_out) n_outer_out[wi] = 0;
+    }
+    for (int wi = 0; wi < P->warps && P->variant != 1; ++wi) {
         orc_warp(I0, I1, B->I1x, B->I1y, u1, u2, w, h, B->I1wx, B->I1wy, B->grad, B->rho_c);
         double error = (double)FLT_MAX;
         int n_in = 0, n_out = 0;

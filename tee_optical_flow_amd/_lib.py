@@ -30,7 +30,7 @@ class TfParams(C.Structure):
     _fields_ = [("tau", C.c_double), ("lambda_", C.c_double), ("theta", C.c_double), ("epsilon", C.c_double),
                 ("scale_step", C.c_double), ("gamma", C.c_double), ("nscales", C.c_int), ("warps", C.c_int),
                 ("inner_iterations", C.c_int), ("outer_iterations", C.c_int), ("median_filtering", C.c_int),
-                ("use_initial_flow", C.c_int), ("algo", C.c_int), ("max_batch", C.c_int)]
+                ("use_initial_flow", C.c_int), ("algo", C.c_int), ("max_batch", C.c_int), ("variant", C.c_int)]
 
 
 class TfDeepflowParams(C.Structure):

@@ -57,6 +57,8 @@ struct tf_handle {
     double alloc_scale_step = 0; int alloc_nscales = 0;
     Geom lv[MAXLEV];
     float* pyr[MAXLEV] = {};
+    float* gxl[MAXLEV] = {}; float* gyl[MAXLEV] = {};   // TF_VARIANT_CUDA: centred gradient of every frame, per level
+    int alloc_variant = 0;
     float *cwx = nullptr, *cwy = nullptr, *crho = nullptr;
     StateBufs sb = {};
     PairCtl* ctl = nullptr;
@@ -190,6 +192,9 @@ int validate_params(tf_handle* h, const tf_params& p)
     if (p.median_filtering != 1 && p.median_filtering != 3 && p.median_filtering != 5)
         return fail(h, TF_ERR_UNSUPPORTED, "medianFiltering must be 1, 3 or 5 (cv::medianBlur on CV_32F), got %d", p.median_filtering);
     if (p.gamma != 0.0) return fail(h, TF_ERR_UNSUPPORTED, "gamma != 0 (illumination term u3) is not implemented");
+    if (p.variant != TF_VARIANT_CPU && p.variant != TF_VARIANT_CUDA) return fail(h, TF_ERR_INVALID_ARG, "variant must be TF_VARIANT_CPU or TF_VARIANT_CUDA, got %d", p.variant);
+    if (p.variant == TF_VARIANT_CUDA && (p.inner_iterations * p.outer_iterations) % 2 != 0)
+        return fail(h, TF_ERR_UNSUPPORTED, "TF_VARIANT_CUDA needs an even iteration count (inner*outer), got %d", p.inner_iterations * p.outer_iterations);
     if (p.use_initial_flow) return fail(h, TF_ERR_UNSUPPORTED, "useInitialFlow is not implemented");
     if (!(p.scale_step > 0.0 && p.scale_step < 1.0)) return fail(h, TF_ERR_INVALID_ARG, "scaleStep must be in (0,1), got %g", p.scale_step);
     if (!(p.theta > 0.0) || !(p.tau > 0.0) || !(p.lambda > 0.0) || !(p.epsilon >= 0.0))
@@ -200,7 +205,7 @@ int validate_params(tf_handle* h, const tf_params& p)
 void free_buffers(tf_handle* h)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    for (int l = 0; l < MAXLEV; ++l) F(h->pyr[l]);
+    for (int l = 0; l < MAXLEV; ++l) { F(h->pyr[l]); F(h->gxl[l]); F(h->gyl[l]); }
     F(h->cwx); F(h->cwy); F(h->crho);
     for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
     F(h->ctl); F(h->errs); F(h->iters_dev);
@@ -234,7 +239,7 @@ int ensure_alloc(tf_handle* h, int H, int W, int B)
     const int want_cap = B < (h->P.max_batch > 0 ? h->P.max_batch : DEFAULT_MAX_BATCH) ? B : (h->P.max_batch > 0 ? h->P.max_batch : DEFAULT_MAX_BATCH);
     const int total = h->P.inner_iterations * h->P.outer_iterations;
     if (h->H == H && h->W == W && h->cap >= want_cap && h->alloc_scale_step == h->P.scale_step &&
-        h->alloc_nscales == h->P.nscales && h->errstride >= total &&
+        h->alloc_nscales == h->P.nscales && h->errstride >= total && h->alloc_variant == h->P.variant &&
         h->iters_cap >= (size_t)h->cap * (size_t)h->nlev * (size_t)h->P.warps * 2)
         return TF_OK;
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -242,6 +247,12 @@ int ensure_alloc(tf_handle* h, int H, int W, int B)
     h->nlev = compute_levels(h->P, H, W, h->lv);
     const size_t cap = (size_t)want_cap, fcap = 2 * cap;
     for (int l = 0; l < h->nlev; ++l) HIPC(h, hipMalloc(&h->pyr[l], fcap * h->lv[l].plane * sizeof(float)));
+    if (h->P.variant == TF_VARIANT_CUDA)
+        for (int l = 0; l < h->nlev; ++l) {
+            HIPC(h, hipMalloc(&h->gxl[l], fcap * h->lv[l].plane * sizeof(float)));
+            HIPC(h, hipMalloc(&h->gyl[l], fcap * h->lv[l].plane * sizeof(float)));
+        }
+    h->alloc_variant = h->P.variant;
     const size_t pl = (size_t)h->lv[0].plane * cap * sizeof(float);
     HIPC(h, hipMalloc(&h->cwx, pl)); HIPC(h, hipMalloc(&h->cwy, pl)); HIPC(h, hipMalloc(&h->crho, pl));
     for (int k = 0; k < 2; ++k) {
@@ -374,9 +385,14 @@ void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 
 // k_warp_lds is instantiated for a few margins (the staged width is a compile-time constant)
 inline int warp_margin_class(int m) { return m <= 0 ? 0 : (m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 12 ? 12 : 16))); }
-void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s)
+void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s, const float* gx = nullptr, const float* gy = nullptr)
 {
     const Geom& g = wa.g;
+    if (h->P.variant == TF_VARIANT_CUDA) {
+        WarpCudaArgs ca; ca.w = wa; ca.gx = gx; ca.gy = gy;
+        hipLaunchKernelGGL(k_warp_cuda, dim3((g.w + 63) / 64, (g.h + 3) / 4, B), dim3(256), 0, s, ca);
+        return;
+    }
     const int M = warp_margin_class(h->warp_margin);
     const dim3 grid((g.w + WL_TW - 1) / WL_TW, (g.h + WL_TH - 1) / WL_TH, B);
     const size_t shm = (size_t)(128 + (WL_TW + 2 * M + 7) * (WL_TH + 2 * M + 7)) * sizeof(float);
@@ -417,21 +433,23 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
         if (!pe) return fail(h, TF_ERR_HIP, "hipEventCreate failed");
         pe->level = -4;
         HIPC(h, hipEventRecord(pe->a, s));
-        launch_warp(h, wa, B, s);
+        launch_warp(h, wa, B, s, h->gxl[l], h->gyl[l]);
         HIPC(h, hipEventRecord(pe->b, s));
-    } else launch_warp(h, wa, B, s);
+    } else launch_warp(h, wa, B, s, h->gxl[l], h->gyl[l]);
     HIPC(h, hipMemsetAsync(h->errs, 0, (size_t)B * h->errstride * sizeof(u64), s));
 
     IterArgs ia;
     ia.wx = h->cwx; ia.wy = h->cwy; ia.rho = h->crho; ia.sb = h->sb; ia.ctl = h->ctl; ia.err = h->errs;
     ia.errstride = h->errstride; ia.thr_q = thr_q; ia.g = g;
     ia.l_t = (float)(P.lambda * P.theta); ia.theta = (float)P.theta; ia.taut = (float)(P.tau / P.theta);
+    ia.variant = P.variant; ia.thr_f = thr_f;
+    const bool cuda_variant = P.variant == TF_VARIANT_CUDA;      // one loop, no median, stops only after odd iterations
     MedArgs ma;
     ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
-    const bool two = h->iter_variant == 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0);
+    const bool two = cuda_variant || (h->iter_variant == 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
         int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
@@ -440,7 +458,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
         const unsigned seq0 = h->launch_seq;
         unsigned checked = seq0;
         for (int it = 0; it <= total && !stop; it += 2) {
-            if (it < total && it % inner == 0 && P.median_filtering > 1) {
+            if (it < total && it % inner == 0 && P.median_filtering > 1 && !cuda_variant) {
                 ma.it = it; ma.utog = utog;
                 ProfEv* pm = h->profile ? prof_next(h) : nullptr;
                 if (pm) { pm->level = -5; HIPC(h, hipEventRecord(pm->a, s)); }
@@ -490,7 +508,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
             }
         }
         hipLaunchKernelGGL(k_stage_end2, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
-                           total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
+                           total, inner, (P.median_filtering > 1 && !cuda_variant) ? 1 : 0, thr_q, l, wi, h->nlev, P.warps, P.variant, thr_f);
         return TF_OK;
     }
     int utog = 0, ptog = 0;
@@ -556,6 +574,9 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
         const double sc = 1.0 / P.scale_step;   // resize(src, Size(), fx, fy): scale = 1/fx
         hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc);
     }
+    if (P.variant == TF_VARIANT_CUDA)
+        for (int l = 0; l < h->nlev; ++l)
+            hipLaunchKernelGGL(k_grad, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l], h->gxl[l], h->gyl[l], h->lv[l]);
     const int L = h->nlev - 1;
     hipLaunchKernelGGL(k_ctl_set, dim3((B + 255) / 256), dim3(256), 0, s, h->ctl, B, 0);
     HIPC(h, hipMemset2DAsync(h->sb.u1[0], (size_t)h->lv[L].splane * sizeof(float), 0, (size_t)h->lv[L].plane * sizeof(float), B, s));
@@ -581,7 +602,7 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
 bool sched_ok(const tf_handle* h, int B)
 {
     const tf_params& P = h->P;
-    return h->sched && h->iter_variant == 2 && P.inner_iterations % 2 == 0 && h->nlev <= SC_MAXLEV && h->lv[0].w <= 1024 &&
+    return h->sched && P.variant == TF_VARIANT_CPU && h->iter_variant == 2 && P.inner_iterations % 2 == 0 && h->nlev <= SC_MAXLEV && h->lv[0].w <= 1024 &&
            B >= h->sched_min_pairs && B <= 1024 && rows_ok(h, h->lv[0], B);
 }
 
@@ -1196,7 +1217,7 @@ TF_API int tf_default_params(tf_params* p)
     if (!p) return TF_ERR_INVALID_ARG;
     p->tau = 0.25; p->lambda = 0.15; p->theta = 0.3; p->epsilon = 0.01; p->scale_step = 0.8; p->gamma = 0.0;
     p->nscales = 5; p->warps = 5; p->inner_iterations = 30; p->outer_iterations = 10; p->median_filtering = 5;
-    p->use_initial_flow = 0; p->algo = TF_ALGO_TVL1; p->max_batch = 0;
+    p->use_initial_flow = 0; p->algo = TF_ALGO_TVL1; p->max_batch = 0; p->variant = TF_VARIANT_CPU;
     return TF_OK;
 }
 
@@ -1969,7 +1990,12 @@ TF_API int tf_dbg_warp(tf_handle* h, const float* I0, const float* I1, const flo
     WarpArgs wa = {};
     wa.pyr = fr; wa.off0 = 0; wa.off1 = 1; wa.sb.u1[0] = du1.p; wa.sb.u2[0] = du2.p; wa.ctl = ctl; wa.tab = h->tab;
     wa.wx = dwx.p; wa.wy = dwy.p; wa.rho = drho.p; wa.g = g;
-    launch_warp(h, wa, 1, h->stream);
+    DBuf dgx, dgy;
+    if (h->P.variant == TF_VARIANT_CUDA) {
+        HIPC(h, hipMalloc(&dgx.p, 2 * (size_t)g.plane * sizeof(float))); HIPC(h, hipMalloc(&dgy.p, 2 * (size_t)g.plane * sizeof(float)));
+        hipLaunchKernelGGL(k_grad, grid64x4(g, 2), dim3(256), 0, h->stream, fr, dgx.p, dgy.p, g);
+    }
+    launch_warp(h, wa, 1, h->stream, dgx.p, dgy.p);
     hipError_t e = hipStreamSynchronize(h->stream);
     (void)hipFree(ctl);
     if (e != hipSuccess) return fail(h, TF_ERR_HIP, "k_warp: %s", hipGetErrorString(e));

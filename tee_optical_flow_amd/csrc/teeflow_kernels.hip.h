@@ -226,6 +226,72 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs a)
             a.wx + po, a.wy + po, a.rho + po, W, H, pitch, x, y);
 }
 
+// ---- cv2.cuda.OpticalFlowDual_TVL1 variant (oracle variant 1) -----------------------------------
+// centeredGradientKernel: 0.5 * (next - prev) with replicate at the border, for every frame of a level
+__global__ __launch_bounds__(256) void k_grad(const float* __restrict__ src, float* __restrict__ gx, float* __restrict__ gy, Geom g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.w || y >= g.h) return;
+    const size_t fo = (size_t)blockIdx.z * g.plane;
+    const float* S = src + fo;
+    const size_t i = (size_t)y * g.pitch + x;
+    const int xp = x + 1 < g.w ? x + 1 : g.w - 1, xm = x > 0 ? x - 1 : 0, yp = y + 1 < g.h ? y + 1 : g.h - 1, ym = y > 0 ? y - 1 : 0;
+    gx[fo + i] = 0.5f * (S[(size_t)y * g.pitch + xp] - S[(size_t)y * g.pitch + xm]);
+    gy[fo + i] = 0.5f * (S[(size_t)yp * g.pitch + x] - S[(size_t)ym * g.pitch + x]);
+}
+
+__device__ __forceinline__ float cuda_bicubic_coeff(float x_)
+{
+    const float x = fabsf(x_);
+    if (x <= 1.0f) return x * x * (1.5f * x - 2.5f) + 1.0f;
+    else if (x < 2.0f) return x * (x * (-0.5f * x + 2.5f) - 4.0f) + 2.0f;
+    return 0.0f;
+}
+
+struct WarpCudaArgs {
+    WarpArgs w;
+    const float *gx, *gy;      // centred gradient of this level's frames (same layout as w.pyr)
+};
+
+// warpBackwardKernel: weight-normalised Catmull-Rom taps over ceil(w-2)..floor(w+2) with clamp addressing, on I1, I1x, I1y
+__global__ __launch_bounds__(256) void k_warp_cuda(WarpCudaArgs A)
+{
+    const WarpArgs& a = A.w;
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
+    if (x >= W || y >= H) return;
+    const int uc = a.ctl[b].ubase & 1;
+    const size_t po = (size_t)b * a.g.splane, idx = (size_t)y * pitch + x;
+    const size_t f1 = (size_t)(a.off1 + b) * a.g.plane;
+    const float* __restrict__ I0 = a.pyr + (size_t)(a.off0 + b) * a.g.plane;
+    const float* __restrict__ I1 = a.pyr + f1;
+    const float* __restrict__ I1x = A.gx + f1;
+    const float* __restrict__ I1y = A.gy + f1;
+    const float u1v = a.sb.u1[uc][po + idx], u2v = a.sb.u2[uc][po + idx];
+    const float wx = (float)x + u1v, wy = (float)y + u2v;
+    const int xmin = (int)ceilf(wx - 2.0f), xmax = (int)floorf(wx + 2.0f);
+    const int ymin = (int)ceilf(wy - 2.0f), ymax = (int)floorf(wy + 2.0f);
+    float sum = 0.0f, sumx = 0.0f, sumy = 0.0f, wsum = 0.0f;
+    for (int cy = ymin; cy <= ymax; ++cy) {
+        const float wyc = cuda_bicubic_coeff(wy - (float)cy);
+        const size_t row = (size_t)clampi(cy, 0, H - 1) * pitch;
+        for (int cx = xmin; cx <= xmax; ++cx) {
+            const float wt = cuda_bicubic_coeff(wx - (float)cx) * wyc;
+            const size_t j = row + clampi(cx, 0, W - 1);
+            sum += wt * I1[j];
+            sumx += wt * I1x[j];
+            sumy += wt * I1y[j];
+            wsum += wt;
+        }
+    }
+    const float coeff = 1.0f / wsum;
+    const float I1w = sum * coeff, gxv = sumx * coeff, gyv = sumy * coeff;
+    a.wx[po + idx] = gxv;
+    a.wy[po + idx] = gyv;
+    a.rho[po + idx] = ((I1w - gxv * u1v) - gyv * u2v) - I0[idx];
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_warp_lds: same arithmetic as k_warp, but the 36 taps of a pixel come from an LDS copy of the I1 tile plus a margin
 // of M pixels (k_warp is L1/TA-bound on its 36 scalar gathers per pixel; ds_read_b32 from a staged tile is ~7x cheaper).
@@ -434,6 +500,8 @@ struct IterArgs {
     float l_t, theta, taut;
     int* host_slot;   // host-mapped word: block 0 publishes how many pairs are still iterating at this launch
     int B;
+    int variant;      // 0 = cv2.optflow CPU DualTVL1; 1 = cv2.cuda.OpticalFlowDual_TVL1 stop rule
+    float thr_f;      // epsilon^2 * area as the float upstream compares with (variant 1)
 };
 
 // Block 0 / wave 0 tells the host how many of the B pairs enter iteration `it` active, through fine-grained
@@ -959,6 +1027,32 @@ __device__ __forceinline__ int pair_mode2(const u64* e, int it, int total, doubl
     return M_EXIT;
 }
 
+// Stop rule of cv2.cuda.OpticalFlowDual_TVL1 (cudaoptflow tvl1flow.cpp procOneScale, restated in oracle/tvl1_oracle.c
+// variant 1): one loop of `total` iterations; the error sum is looked at only on odd iterations n, and only once the
+// running prevError (last seen error, minus the threshold for every iteration without a look) has dropped below the
+// threshold.  A stop can therefore only follow an odd iteration = the second one of a launch: no REPLAY in this variant.
+// Replays the recurrence over iterations [0, it): M_NORMAL if the pair still iterates at launch `it`, else M_EXIT with
+// *n_it = iterations executed.
+__device__ __forceinline__ int pair_mode_cuda(const u64* e, int it, int total, float thr, int* n_it)
+{
+    float prev = 0.0f;
+    for (int n = 0; n < it; ++n) {
+        const bool calc = thr > 0.0f && (n & 1) && prev < thr;
+        if (calc) {
+            const float err = (float)((double)e[n] * 0x1p-30);
+            prev = err;
+            if (!(err > thr)) { if (n_it) *n_it = n + 1; return M_EXIT; }
+        } else prev -= thr;
+    }
+    if (n_it) *n_it = total;
+    return it < total ? M_NORMAL : M_EXIT;
+}
+
+__device__ __forceinline__ int pair_mode(const u64* e, int it, int total, double thr_q, int variant, float thr_f)
+{
+    return variant ? pair_mode_cuda(e, it, total, thr_f, nullptr) : pair_mode2(e, it, total, thr_q);
+}
+
 // Work items of a tvl1_iter launch when the strips are sized ON THE DEVICE from the number of pairs that still
 // iterate (`n`): one round of at most `slots` resident blocks (slots = CUs x blocks per CU), each marching a strip that is
 // as long as that allows -- a lock-step batch loses a third of its time otherwise (a launch with 1024 blocks on 768 slots
@@ -988,7 +1082,7 @@ __device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
     if (a.host_slot && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
         int c = 0;
         for (int b2 = threadIdx.x; b2 < a.B; b2 += 64)
-            c += pair_mode2(a.err + (size_t)b2 * a.errstride, a.it, A.total, a.thr_q) != M_EXIT ? 1 : 0;
+            c += pair_mode(a.err + (size_t)b2 * a.errstride, a.it, A.total, a.thr_q, a.variant, a.thr_f) != M_EXIT ? 1 : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
         if (threadIdx.x == 0) __hip_atomic_store(a.host_slot, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1026,7 +1120,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         const int nchunk = (a.B + 63) >> 6, nw = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
         for (int c = wv; c < nchunk; c += nw) {
             const int pb = c * 64 + ln;
-            const bool on = pb < a.B && pair_mode2(a.err + (size_t)pb * a.errstride, a.it, A.total, a.thr_q) != M_EXIT;
+            const bool on = pb < a.B && pair_mode(a.err + (size_t)pb * a.errstride, a.it, A.total, a.thr_q, a.variant, a.thr_f) != M_EXIT;
             const u64 m = __ballot(on);
             if (ln == 0) sred[c] = m;
         }
@@ -1047,7 +1141,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         __syncthreads();                                    // sred is reused for the error sums below
     }
     u64* errb = a.err + (size_t)b * a.errstride;
-    const int mode = pair_mode2(errb, a.it, A.total, a.thr_q);   // block-uniform
+    const int mode = pair_mode(errb, a.it, A.total, a.thr_q, a.variant, a.thr_f);   // block-uniform
     if (mode == M_EXIT) return;
     const bool replay = mode == M_REPLAY;
     const PairCtl c = a.ctl[b];
@@ -1323,7 +1417,7 @@ __global__ __launch_bounds__(256) void k_iter2_tile(Iter2Args A)
     publish_active_count2(A);
     const int b = blockIdx.z;
     u64* errb = a.err + (size_t)b * a.errstride;
-    const int mode = pair_mode2(errb, a.it, A.total, a.thr_q);                  // block-uniform
+    const int mode = pair_mode(errb, a.it, A.total, a.thr_q, a.variant, a.thr_f);   // block-uniform
     if (mode == M_EXIT) return;
     const bool replay = mode == M_REPLAY;
     const PairCtl c = a.ctl[b];
@@ -1482,15 +1576,18 @@ __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
 
 // stage end for the two-iterations-per-launch schedule: a pair took part in ceil(n_it/2) launches
 __global__ void k_stage_end2(const u64* __restrict__ err, int errstride, PairCtl* ctl, int* iters, int B,
-                             int total, int inner, int median_on, double thr_q, int level, int warp, int nlev, int warps)
+                             int total, int inner, int median_on, double thr_q, int level, int warp, int nlev, int warps,
+                             int variant, float thr_f)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const u64* e = err + (size_t)b * errstride;
     int n_it = total;
-    for (int j = 0; j < total; ++j)
-        if (!((double)e[j] > thr_q)) { n_it = j + 1; break; }
-    const int n_out = n_it > 0 ? (n_it - 1) / inner + 1 : 0;
+    if (variant) (void)pair_mode_cuda(e, total, total, thr_f, &n_it);
+    else
+        for (int j = 0; j < total; ++j)
+            if (!((double)e[j] > thr_q)) { n_it = j + 1; break; }
+    const int n_out = variant ? 0 : (n_it > 0 ? (n_it - 1) / inner + 1 : 0);      // the CUDA variant has no outer loop / median
     const int launches = (n_it + 1) / 2;
     PairCtl c = ctl[b];
     c.ubase = (c.ubase + launches + (median_on ? n_out : 0)) & 1;

@@ -100,6 +100,10 @@ class DenseFlow:
         p = _lib.TfParams()
         _lib.check(self._L.tf_default_params(C.byref(p)), None, "tf_default_params")
         p.max_batch = int(max_batch)
+        variant = params.pop("variant", "cpu")
+        if variant not in ("cpu", "cuda", 0, 1):
+            raise OpticalFlowCalculationError(f"variant must be 'cpu' or 'cuda', got {variant!r}")
+        p.variant = 1 if variant in ("cuda", 1) else 0          # TF_VARIANT_CUDA: cv2.cuda.OpticalFlowDual_TVL1 semantics (row a5)
         for k, v in params.items():
             key = "lambda_" if k in ("lambda", "lambda_") else k
             if not hasattr(p, key):
@@ -309,3 +313,10 @@ def createOptFlow_DeepFlow(device_id=0, **kw):
 def createOptFlow_DualTVL1(device_id=0, **kw):
     """Name-compatible factory for cv2.optflow.createOptFlow_DualTVL1() (reference :577)."""
     return DenseFlow(device_id=device_id, **kw)
+
+
+def cuda_OpticalFlowDual_TVL1_create(device_id=0, **kw):
+    """Counterpart of cv2.cuda.OpticalFlowDual_TVL1.create() (reference :575): the CUDA branch's semantics -- 300 iterations
+    in one loop per warp, no median filtering, error looked at on odd iterations only, weight-normalised Catmull-Rom warp
+    with clamp addressing (TF_VARIANT_CUDA).  As on the reference's CUDA branch, nothing is set on it."""
+    return DenseFlow(device_id=device_id, variant="cuda", **kw)

@@ -26,12 +26,16 @@ from .frames import condition_frames
 logger = logging.getLogger(__name__)
 
 
-def make_flow_model(OF_algo="TVL1", config=None, device_id=0):
-    """Reference :564-578.  Both TV-L1 branches (cv2.cuda / cv2.optflow) map to the one HIP engine; unlike the
-    reference's CUDA branch (Appendix C.2) lambda_value IS applied."""
+def make_flow_model(OF_algo="TVL1", config=None, device_id=0, tvl1_variant="cpu"):
+    """Reference :564-578.  tvl1_variant='cpu' (default, the parity target) is the reference's non-CUDA branch:
+    createOptFlow_DualTVL1() + setLambda(config.lambda_value) (:577-578).  tvl1_variant='cuda' reproduces what the reference
+    runs on a CUDA box (:572-575): cv2.cuda.OpticalFlowDual_TVL1.create() with NOTHING set on it -- lambda_value is
+    silently ignored there, and so it is here."""
     if config is None:
         config = default_optical_flow_config()
     if OF_algo == "TVL1":
+        if tvl1_variant == "cuda":
+            return DenseFlow(device_id=device_id, variant="cuda")
         m = DenseFlow(device_id=device_id)
         m.setLambda(config.lambda_value)
         return m
