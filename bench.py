@@ -126,7 +126,7 @@ def pmc_child_passes(algo, out_dir, tag="live"):
         d = os.path.join(out_dir, f"pmc_{tag}_{algo}_{ctr}")
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-include-regex", kern, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile",
-               "--lanes", "1", "--no-deepflow", "--algo", algo] + (["--batch", "64"] if algo != "TVL1" else [])
+               "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo] + (["--batch", "64"] if algo != "TVL1" else [])
         env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
         r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         if r.returncode != 0:
@@ -436,6 +436,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         out["collective"] = collective
         if gather_ok is not None:
             out["allgather_checksums_match"] = gather_ok
+    if rank == 0 and not a.steps_only:
         # single-pair latency (BASELINE configs[1] as a latency number), outside the timed region
         lat_eng = T.DenseFlow(device_id=local_rank, max_batch=1, algo=algo)
         for k, v in tuning:
@@ -496,6 +497,7 @@ def main():
                                                        "processes under rocprofv3 (adds ~1-2 min), so roofline.traffic is measured in this run")
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_live"))
     ap.add_argument("--round-tag", default="r02")
+    ap.add_argument("--steps-only", action="store_true", help="only the timed steps: no single-pair latency, no PCIe step (what the counter passes profile)")
     ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")

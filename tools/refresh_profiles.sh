@@ -1,23 +1,26 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): rocprofv3 kernel-trace summaries of the bench commands and the two PMC passes
-# behind profiles/hbm_traffic.json.  Outputs under gpurun_out/prof/; tools/collect_profiles.py copies the summaries
-# into profiles/.   usage: bash tools/refresh_profiles.sh <round-tag, e.g. r01>
-set -e
-TAG=${1:-r01}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof
+# Runs on the GPU box (through gpurun): everything profiles/ is built from, for the CURRENT kernel build.
+#   1. rocprofv3 --kernel-trace --stats summaries of the default bench command and of its single-lane form
+#   2. python3 bench.py --pmc : the FETCH_SIZE / WRITE_SIZE passes (children of bench.py, one counter per pass) for the
+#      DualTVL1 and the DeepFlow leg, and the JSON line that carries the traffic measured that way
+#   3. SQ / GRBM counter passes over the dominant kernels (tools/pmc_sq.sh)
+# Outputs under gpurun_out/prof_<tag>/ ; tools/collect_profiles.py <tag> condenses them into profiles/.
+# usage: bash tools/refresh_profiles.sh <round-tag, e.g. r02>
+set -u
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd /tmp
 run_stats() {   # name, bench args...
   local name=$1; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 bench.py "$@" > $OUT/${TAG}_bench_$name.json 2> $OUT/$name.err
-  echo "stats $name done"
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/${TAG}_bench_$name.json 2> $OUT/$name.err
+  echo "stats $name rc=$?"
 }
 run_stats default
-run_stats lanes1 --lanes 1
-run_stats deepflow_lanes1 --algo deepflow --batch 64 --steps 2 --lanes 1 --cpu-sample 2
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-include-regex k_iter2 --output-format csv -d $OUT/pmc_$c -o pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --lanes 1 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
-  echo "pmc $c done"
-done
-find $OUT -name "*.csv" | head -40
+run_stats lanes1 --lanes 1 --no-cpu-baseline
+timeout -k 10 900 python3 $GRAFT_REPO_ROOT/bench.py --pmc --pmc-dir $OUT/pmc_live --round-tag $TAG > $OUT/${TAG}_bench_pmc.json 2> $OUT/bench_pmc.err
+echo "bench --pmc rc=$?"
+cd $GRAFT_REPO_ROOT
+bash tools/pmc_sq.sh $TAG TVL1 > $OUT/pmc_sq_tvl1.log 2>&1; tail -2 $OUT/pmc_sq_tvl1.log
+bash tools/pmc_sq.sh $TAG deepflow > $OUT/pmc_sq_df.log 2>&1; tail -2 $OUT/pmc_sq_df.log
