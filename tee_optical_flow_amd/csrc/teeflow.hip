@@ -105,6 +105,9 @@ struct tf_handle {
     int sor_nt = 1024;           // DeepFlow SOR tile kernel: threads per block (256 | 512 | 1024).  Fewer slots per thread = fewer
                                  // registers (167 -> 95 -> 60 VGPRs at 3-4 sweeps) = 3 -> 4 -> 8 waves per SIMD: 411 / 470 / 491 pairs/s
     int sor_whole = 1;           // DeepFlow: levels up to 96 x 96 run a whole fixed-point iteration's SOR in one launch
+    int sor_diet = 0;            // DeepFlow SOR with weights, neighbour addresses and diagonal reciprocals hoisted out of the sweeps: bit-identical,
+                                 // a third fewer instructions per update, but ~110 instead of 60 VGPRs = one 1024-thread block per CU instead
+                                 // of two: 384 instead of 494 pairs/s (64 pairs @512^2).  The kernel lives on its resident waves; kept as a knob
     int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
     int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
                                  // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
@@ -126,9 +129,6 @@ struct tf_handle {
                                  // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
-    int small_w = 0, small_slots_pct = 100, small_ry = 0;   // experiments: levels at most small_w px wide size their strips for a
-                                                            // fraction of the resident-block slots / take small_ry rows per step
-    int mid_lo = 0, mid_hi = 0, mid_ry = 0;                 // experiments: levels with mid_lo < w <= mid_hi take mid_ry rows per step
     // free-running pair scheduler (teeflow_sched.hip.h): every pair walks through its own stages; used when the batch is
     // large enough for the row strips, the level count fits SC_MAXLEV and the frames are at most 1024 px wide
     int sched = 0, sched_min_pairs = 24, sched_lag = 2, misc_blocks_per_cu = 8;
@@ -315,9 +315,7 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
     const int qx = (g.w + 3) / 4;
     int ry = 256 / qx;
     if (ry < 1) ry = 1;
-    int forced = h->force_ry;
-    if (g.w <= h->small_w && h->small_ry > 0) forced = h->small_ry;
-    if (g.w > h->mid_lo && g.w <= h->mid_hi && h->mid_ry > 0) forced = h->mid_ry;
+    const int forced = h->force_ry;
     if (forced > 0 && qx * forced <= 512) ry = forced;
     *QX = qx; *RY = ry;
     *threads = (qx * ry <= 256 && forced <= 0) ? 256 : (qx * ry + 63) / 64 * 64;   // forced shapes: no idle waves
@@ -354,7 +352,6 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
             }
             slots = f->second;
         }
-        if (g.w <= h->small_w && h->small_slots_pct > 0 && h->small_slots_pct < 100) slots = slots * h->small_slots_pct / 100;
         int items = 1;
         for (int n = 1; n <= B; ++n) {
             int r, sn;
@@ -837,34 +834,36 @@ void df_gauss3(float sigma, float* k0, float* k1)
 }
 
 template <int S>
-void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s, int nt = 256)
+void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s, int nt = 256, int diet = 1)
 {
     constexpr int RW = 64 + 4 * S, RH = 32 + 4 * S;
     const dim3 grid((g.w + 63) / 64, (g.h + 31) / 32, B);
     const size_t shm = (size_t)3 * RW * RH * sizeof(float);
-    if (nt == 1024) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024>), grid, dim3(1024), shm, s, d, g, omega, S);
-    else if (nt == 512) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 512>), grid, dim3(512), shm, s, d, g, omega, S);
-    else hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 256>), grid, dim3(256), shm, s, d, g, omega, S);
+    if (nt == 1024 && diet) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 1>), grid, dim3(1024), shm, s, d, g, omega, S);
+    else if (nt == 1024) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 0>), grid, dim3(1024), shm, s, d, g, omega, S);
+    else if (nt == 512) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 512, 0>), grid, dim3(512), shm, s, d, g, omega, S);
+    else hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 256, 0>), grid, dim3(256), shm, s, d, g, omega, S);
 }
 
 // levels that fit one 96 x 96 region: all sweeps of a fixed-point iteration in ONE launch, one block of 1024 threads per pair
 // (a 64 x 64 region for the smallest levels: 2 instead of 5 slots per thread)
 constexpr int DF_WHOLE = 96;
-template <int RGN>
+template <int RGN, int DIET>
 void launch_sor_whole_t(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
 {
     constexpr size_t shm = (size_t)(3 * RGN * RGN + RGN / 2 + 4) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<0, RGN, RGN, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<0, RGN, RGN, 1024, DIET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr = true;
     }
-    hipLaunchKernelGGL((k_df_sor_fused<0, RGN, RGN, 1024>), dim3(1, 1, B), dim3(1024), shm, s, d, g, omega, sweeps);
+    hipLaunchKernelGGL((k_df_sor_fused<0, RGN, RGN, 1024, DIET>), dim3(1, 1, B), dim3(1024), shm, s, d, g, omega, sweeps);
 }
-void launch_sor_whole(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
+void launch_sor_whole(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s, int diet)
 {
-    if (g.w <= 64 && g.h <= 64) launch_sor_whole_t<64>(d, g, B, omega, sweeps, s);
-    else launch_sor_whole_t<DF_WHOLE>(d, g, B, omega, sweeps, s);
+    // the 96 x 96 region gives a thread 5 slots: the hoisted per-slot values do not fit its registers, it keeps the plain form
+    if (g.w <= 64 && g.h <= 64) { if (diet) launch_sor_whole_t<64, 1>(d, g, B, omega, sweeps, s); else launch_sor_whole_t<64, 0>(d, g, B, omega, sweeps, s); }
+    else launch_sor_whole_t<DF_WHOLE, 0>(d, g, B, omega, sweeps, s);
 }
 
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
@@ -893,7 +892,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             }
             ++h->iter_launches;
             h->df_sor_bytes += (double)left * g.w * g.h * B * 40.0;
-            launch_sor_whole(d, g, B, c.omega, left, s);
+            launch_sor_whole(d, g, B, c.omega, left, s, h->sor_diet);
             if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
             left = 0;
@@ -917,11 +916,11 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             ++h->iter_launches;
             h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;   // one sweep: 8 planes read + du, dv written
             switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
-                case 1: launch_sor_fused<1>(d, g, B, c.omega, s, h->sor_nt); break;
-                case 2: launch_sor_fused<2>(d, g, B, c.omega, s, h->sor_nt); break;
-                case 3: launch_sor_fused<3>(d, g, B, c.omega, s, h->sor_nt); break;
-                case 4: launch_sor_fused<4>(d, g, B, c.omega, s, h->sor_nt); break;
-                default: launch_sor_fused<5>(d, g, B, c.omega, s, h->sor_nt); break;
+                case 1: launch_sor_fused<1>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
+                case 2: launch_sor_fused<2>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
+                case 3: launch_sor_fused<3>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
+                case 4: launch_sor_fused<4>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
+                default: launch_sor_fused<5>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
             }
             if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
@@ -1142,9 +1141,8 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
         t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu; t->sched_overlap = h->sched_overlap;
-        t->small_w = h->small_w; t->small_slots_pct = h->small_slots_pct; t->small_ry = h->small_ry; t->mid_lo = h->mid_lo; t->mid_hi = h->mid_hi; t->mid_ry = h->mid_ry;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1401,18 +1399,13 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "slots") h->slots_override = value;
     else if (n == "tile_max_w") h->tile_max_w = value;
     else if (n == "sor_whole") h->sor_whole = value;
+    else if (n == "sor_diet") h->sor_diet = value;
     else if (n == "sor_nt") h->sor_nt = value == 1024 ? 1024 : (value == 512 ? 512 : 256);
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
-    else if (n == "small_w") h->small_w = value;
-    else if (n == "small_slots_pct") h->small_slots_pct = value;
-    else if (n == "small_ry") h->small_ry = value;
-    else if (n == "mid_lo") h->mid_lo = value;
-    else if (n == "mid_hi") h->mid_hi = value;
-    else if (n == "mid_ry") h->mid_ry = value;
     else if (n == "sched") h->sched = value;
     else if (n == "sched_min_pairs") h->sched_min_pairs = value < 1 ? 1 : value;
     else if (n == "sched_lag") h->sched_lag = value < 1 ? 1 : (value > 64 ? 64 : value);

@@ -211,8 +211,33 @@ __global__ __launch_bounds__(256) void k_df_sor(DfBufs d, Geom g, int color, flo
 // conflicts of a stride-2 access), and a slot's two pixels are fetched / written back with one 8-byte access per plane.
 // S > 0: S sweeps on TW x TH tiles with a 2S halo.  S == 0: the region IS the image (W <= TW, H <= TH; one block per pair,
 // no halo, nothing recomputed) and `nsw` sweeps -- a whole fixed-point iteration's SOR -- run in one launch.
-template <int S, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 && S > 0 ? 8 : 1, NT == 1024 && S > 0 ? 8 : 8))) void k_df_sor_fused(DfBufs d, Geom g, float omega, int nsw)
+// DIET = 1 (knob sor_diet, off by default -- see the measurement at its declaration in teeflow.hip): what never changes during the sweeps is hoisted out of them -- per (colour, slot) the four neighbour
+// weights already masked by the image border, the LDS addresses of the pixel and its four neighbours (a missing neighbour
+// points at the pixel itself and carries weight 0), and the two diagonals pre-scaled with their refined reciprocals, so
+// that each of the two IEEE divisions of an update is the 7-instruction tail of the correctly rounded sequence (div1s)
+// instead of the full one.  Same products, same sums, same quotients -> same bits (a block whose diagonals leave the
+// range div1s is exact for falls back to the plain division).  The SOR kernel is VALU-bound (profiles/r02_sq_counters.json:
+// the vector ALU is busy ~90-100 % of a launch), so instructions are what it pays for: 12 selects, 3 weight loads, the
+// address arithmetic and 2 reciprocal set-ups less per update.
+__device__ __forceinline__ float rcp1s(float bs)
+{
+    const float r = __builtin_amdgcn_rcpf(bs);
+    const float e = __builtin_fmaf(-bs, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div1s(float a, float b, float bs, float rs)     // a / b, see div2s in teeflow_kernels.hip.h
+{
+    const float as = a * 0x1p64f;
+    float q = as * rs;
+    float e = __builtin_fmaf(-bs, q, as);
+    q = __builtin_fmaf(e, rs, q);
+    e = __builtin_fmaf(-bs, q, as);
+    q = __builtin_fmaf(e, rs, q);
+    return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+
+template <int S, int TW, int TH, int NT, int DIET = 0>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 && S > 0 && !DIET ? 8 : 1, NT == 1024 && S > 0 && !DIET ? 8 : 8))) void k_df_sor_fused(DfBufs d, Geom g, float omega, int nsw)
 {
     constexpr int HL = 2 * S, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + NT - 1) / NT;
     constexpr int PAD = S == 0 ? HW + 4 : 0;     // whole-image form: row 0 is updated, its (unused) "row above" address must stay inside LDS
@@ -271,8 +296,60 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 &
     }
     __syncthreads();
     const int sweeps = S > 0 ? S : nsw;
+    bool generic = !DIET;
+    if constexpr (DIET) {
+        float wL[2][NS], wR[2][NS], wU[2][NS], wD[2][NS], s11[2][NS], r11[2][NS], s22[2][NS], r22[2][NS];
+        int oS[2][NS], oL[2][NS], oR[2][NS], oU[2][NS], oD[2][NS];     // float offsets into smem of du at the pixel / its neighbours
+        int bad = 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const unsigned f = flg[c][k];
+                const int q = threadIdx.x + k * NT, par = (f >> 6) & 1;
+                const int A = ODU + par * NSLOT, Bo = ODU + (par ^ 1) * NSLOT;
+                const int li = par ? q : q - 1, ri = par ? q + 1 : q;
+                wL[c][k] = wR[c][k] = wU[c][k] = wD[c][k] = 0.f;
+                oS[c][k] = oL[c][k] = oR[c][k] = oU[c][k] = oD[c][k] = A + (q < NSLOT ? q : 0);
+                s11[c][k] = s22[c][k] = 0x1p64f; r11[c][k] = r22[c][k] = 0x1p-64f;
+                if (f & 1u) {
+                    const float ws = smem[OWG - ODU + A + q];
+                    if (f & 2u) { wL[c][k] = smem[OWG - ODU + Bo + li]; oL[c][k] = Bo + li; }
+                    if (f & 4u) { wR[c][k] = ws; oR[c][k] = Bo + ri; }
+                    if (f & 8u) { wU[c][k] = smem[OWG - ODU + A + q - HW]; oU[c][k] = A + q - HW; }
+                    if (f & 16u) { wD[c][k] = ws; oD[c][k] = A + q + HW; }
+                    s11[c][k] = a11[c][k] * 0x1p64f; r11[c][k] = rcp1s(s11[c][k]);
+                    s22[c][k] = a22[c][k] * 0x1p64f; r22[c][k] = rcp1s(s22[c][k]);
+                    // div1s is the exact quotient for 2^-24 < |b| < 2^60 (and |a| < 2^60): keep well inside
+                    bad |= !(fabsf(a11[c][k]) > 0x1p-20f && fabsf(a11[c][k]) < 0x1p50f && fabsf(a22[c][k]) > 0x1p-20f && fabsf(a22[c][k]) < 0x1p50f);
+                }
+            }
+        generic = __builtin_amdgcn_readfirstlane(__syncthreads_or(bad)) != 0;     // block-uniform: such a block takes the plain form below
 #pragma unroll 1
-    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int sw = 0; sw < (generic ? 0 : sweeps); ++sw) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    if (flg[c][k] & 1u) {
+                        const float* P = smem;
+                        constexpr int DV = 2 * NSLOT;                    // dv planes sit 2 * NSLOT floats behind the du planes
+                        const float sigmaU = wL[c][k] * P[oL[c][k]] + wR[c][k] * P[oR[c][k]] + wU[c][k] * P[oU[c][k]] + wD[c][k] * P[oD[c][k]];
+                        const float sigmaV = wL[c][k] * P[oL[c][k] + DV] + wR[c][k] * P[oR[c][k] + DV] + wU[c][k] * P[oU[c][k] + DV] + wD[c][k] * P[oD[c][k] + DV];
+                        float du = P[oS[c][k]], dv = P[oS[c][k] + DV];
+                        const float n1 = sigmaU + b1[c][k] - dv * a12[c][k];
+                        du += omega * (div1s(n1, a11[c][k], s11[c][k], r11[c][k]) - du);
+                        const float n2 = sigmaV + b2[c][k] - du * a12[c][k];
+                        dv += omega * (div1s(n2, a22[c][k], s22[c][k], r22[c][k]) - dv);
+                        smem[oS[c][k]] = du; smem[oS[c][k] + DV] = dv;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll 1
+    for (int sw = 0; sw < (generic ? sweeps : 0); ++sw) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
