@@ -3,7 +3,8 @@
 #   1. rocprofv3 --kernel-trace --stats summaries of the default bench command and of its single-lane form
 #   2. python3 bench.py --pmc : the FETCH_SIZE / WRITE_SIZE passes (children of bench.py, one counter per pass) for the
 #      DualTVL1 and the DeepFlow leg, and the JSON line that carries the traffic measured that way
-#   3. SQ / GRBM counter passes over the dominant kernels (tools/pmc_sq.sh)
+#   3. per-launch profile of the lock-step driver (tools/launch_profile.py) and the arithmetic ablation probe
+#   4. SQ / GRBM counter passes over the dominant kernels (tools/pmc_sq.sh)
 # Outputs under gpurun_out/prof_<tag>/ ; tools/collect_profiles.py <tag> condenses them into profiles/.
 # usage: bash tools/refresh_profiles.sh <round-tag, e.g. r02>
 set -u
@@ -22,5 +23,7 @@ run_stats lanes1 --lanes 1 --no-cpu-baseline
 timeout -k 10 900 python3 $GRAFT_REPO_ROOT/bench.py --pmc --pmc-dir $OUT/pmc_live --round-tag $TAG > $OUT/${TAG}_bench_pmc.json 2> $OUT/bench_pmc.err
 echo "bench --pmc rc=$?"
 cd $GRAFT_REPO_ROOT
+timeout -k 10 200 python3 tools/launch_profile.py --batch 64 > $OUT/${TAG}_launch_profile_b64.txt 2>&1; echo "launch_profile rc=$?"
+[ -x tools/microbench/ablate_probe ] && (cd tools/microbench && timeout -k 10 200 ./ablate_probe > $OUT/${TAG}_ablate_probe.txt 2>&1; echo "ablate rc=$?")
 bash tools/pmc_sq.sh $TAG TVL1 > $OUT/pmc_sq_tvl1.log 2>&1; tail -2 $OUT/pmc_sq_tvl1.log
 bash tools/pmc_sq.sh $TAG deepflow > $OUT/pmc_sq_df.log 2>&1; tail -2 $OUT/pmc_sq_df.log
