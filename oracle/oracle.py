@@ -27,8 +27,10 @@ class OrcParams(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "tvl1_oracle.c")):
+    libs = [_LIB_PATH, os.path.join(_HERE, "libdeepflow_oracle.so"), os.path.join(_HERE, "libteeflow_cpu.so")]
+    srcs = [os.path.join(_HERE, f) for f in ("tvl1_oracle.c", "deepflow_oracle.c", "teeflow_cpu_abi.c")]
+    if force or not all(os.path.exists(l) for l in libs) or \
+            min(os.path.getmtime(l) for l in libs) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 

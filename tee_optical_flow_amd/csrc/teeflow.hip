@@ -1391,7 +1391,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     const std::string n(name);
     if (n == "iter_variant") h->iter_variant = value;
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
-    else if (n == "lag") h->lag = value > 0 ? (value < SLOT_RING / 2 ? value : SLOT_RING / 2) : DEFAULT_LAG;   // unread slots must never be overwritten
+    else if (n == "lag") h->lag = value < 0 ? DEFAULT_LAG : (value < SLOT_RING / 2 ? value : SLOT_RING / 2);   // 0 = wait for every launch's report (it is published at the launch's start); unread slots must never be overwritten
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;

@@ -1,0 +1,61 @@
+"""Host-side logic of bench.py that needs no GPU: the kernel-source fingerprint that decides whether a stored PMC / ISA
+record may be used, the profiler detection that keeps child processes away from a GPU-initialised process, the input
+cache, and the FETCH_SIZE factors."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_fingerprint_gates_stored_records(tmp_path, monkeypatch):
+    import bench
+    fp = bench.kernel_source_fingerprint()
+    assert len(fp) == 16 and fp == bench.kernel_source_fingerprint()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_fingerprint", lambda: fp)
+    rec, why = bench.stored_record("hbm_traffic.json", "k_iter2_rows")
+    assert rec is None and "missing" in why
+    (prof / "hbm_traffic.json").write_text(json.dumps({"k_iter2_rows": {"bytes_per_launch": 1.0, "source_fingerprint": "0" * 16, "round": "r01"}}))
+    rec, why = bench.stored_record("hbm_traffic.json", "k_iter2_rows")
+    assert rec is None and "not used" in why                     # another build's counters are never replayed
+    (prof / "hbm_traffic.json").write_text(json.dumps({"k_iter2_rows": {"bytes_per_launch": 5.0, "source_fingerprint": fp, "round": "r02"}}))
+    rec, why = bench.stored_record("hbm_traffic.json", "k_iter2_rows")
+    assert why is None and rec["bytes_per_launch"] == 5.0
+    rec, why = bench.stored_record("hbm_traffic.json", "k_df_sor_fused")
+    assert rec is None and "no record" in why
+
+
+def test_profiler_detection_and_input_cache(tmp_path, monkeypatch):
+    import bench
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    assert not bench.under_profiler()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler()
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    a0, a1 = bench.make_inputs([3, 4], 40, 48)                   # under a "profiler": generated in-process, no pool
+    assert a0.shape == (2, 40, 48) and a0.dtype == np.uint8 and any(f.startswith("teeflow_bench_inputs_") for f in os.listdir(tmp_path))
+    b0, b1 = bench.make_inputs([3, 4], 40, 48)                   # second call: from the cache, identical
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+    from tee_optical_flow_amd.synth import speckle_pair
+    assert np.array_equal(a0[1], speckle_pair(4, 40, 48)[0])
+
+
+def test_fetch_factors_and_committed_records_are_well_formed():
+    import bench
+    assert bench.FETCH_FACTOR == {"TVL1": 2.0, "deepflow": 1.0}
+    for name in ("hbm_traffic.json", "isa_stats.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            d = json.load(open(p))
+            for kern, rec in d.items():
+                assert "source_fingerprint" in rec and len(rec["source_fingerprint"]) == 16, (name, kern)
