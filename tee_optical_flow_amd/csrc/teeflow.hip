@@ -105,6 +105,7 @@ struct tf_handle {
     int sor_nt = 1024;           // DeepFlow SOR tile kernel: threads per block (256 | 512 | 1024).  Fewer slots per thread = fewer
                                  // registers (167 -> 95 -> 60 VGPRs at 3-4 sweeps) = 3 -> 4 -> 8 waves per SIMD: 411 / 470 / 491 pairs/s
     int sor_whole = 1;           // DeepFlow: levels up to 96 x 96 run a whole fixed-point iteration's SOR in one launch
+    int sor_mw = 1;              // DeepFlow SOR tile form: edge-weight planes in LDS, unconditional neighbour loads (teeflow_deepflow.hip.h)
     int sor_diet = 0;            // DeepFlow SOR with weights, neighbour addresses and diagonal reciprocals hoisted out of the sweeps: bit-identical,
                                  // a third fewer instructions per update, but ~110 instead of 60 VGPRs = one 1024-thread block per CU instead
                                  // of two: 384 instead of 494 pairs/s (64 pairs @512^2).  The kernel lives on its resident waves; kept as a knob
@@ -834,11 +835,21 @@ void df_gauss3(float sigma, float* k0, float* k1)
 }
 
 template <int S>
-void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s, int nt = 256, int diet = 1)
+void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s, int nt = 256, int diet = 0, int mw = 0)
 {
     constexpr int RW = 64 + 4 * S, RH = 32 + 4 * S;
     const dim3 grid((g.w + 63) / 64, (g.h + 31) / 32, B);
     const size_t shm = (size_t)3 * RW * RH * sizeof(float);
+    if (nt == 1024 && mw && !diet) {
+        const size_t shm4 = (size_t)4 * RW * RH * sizeof(float);             // du, dv, WX, WY x two parities
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<S, 64, 32, 1024, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm4);
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 0, 1>), grid, dim3(1024), shm4, s, d, g, omega, S);
+        return;
+    }
     if (nt == 1024 && diet) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 1>), grid, dim3(1024), shm, s, d, g, omega, S);
     else if (nt == 1024) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 0>), grid, dim3(1024), shm, s, d, g, omega, S);
     else if (nt == 512) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 512, 0>), grid, dim3(512), shm, s, d, g, omega, S);
@@ -916,11 +927,11 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             ++h->iter_launches;
             h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;   // one sweep: 8 planes read + du, dv written
             switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
-                case 1: launch_sor_fused<1>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
-                case 2: launch_sor_fused<2>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
-                case 3: launch_sor_fused<3>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
-                case 4: launch_sor_fused<4>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
-                default: launch_sor_fused<5>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet); break;
+                case 1: launch_sor_fused<1>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
+                case 2: launch_sor_fused<2>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
+                case 3: launch_sor_fused<3>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
+                case 4: launch_sor_fused<4>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
+                default: launch_sor_fused<5>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
             }
             if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
@@ -1141,7 +1152,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_mw = h->sor_mw; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
         t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu; t->sched_overlap = h->sched_overlap;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
@@ -1400,6 +1411,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "tile_max_w") h->tile_max_w = value;
     else if (n == "sor_whole") h->sor_whole = value;
     else if (n == "sor_diet") h->sor_diet = value;
+    else if (n == "sor_mw") h->sor_mw = value;
     else if (n == "sor_nt") h->sor_nt = value == 1024 ? 1024 : (value == 512 ? 512 : 256);
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);

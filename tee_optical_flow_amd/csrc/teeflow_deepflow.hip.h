@@ -236,9 +236,17 @@ __device__ __forceinline__ float div1s(float a, float b, float bs, float rs)    
     return __builtin_amdgcn_div_fixupf(q, b, a);
 }
 
-template <int S, int TW, int TH, int NT, int DIET = 0>
+// MW = 1 (tile form only, S > 0): the staged weight plane is replaced by two EDGE-weight planes, WX[p] = w[p] if the pixel has a
+// right neighbour in the image else 0 and WY[p] likewise for the pixel below (0 outside the image).  The four weights of an
+// update are then WX[self], WX[left], WY[self], WY[up] and all of its loads are unconditional: a neighbour that does not
+// exist lies outside the image, where du, dv and the edge weights are staged as 0, so its product is the same 0 * 0 the
+// flag-guarded form computes.  Same operations in the same order -> same bits; what goes away is the exec-mask juggling the
+// compiler makes of the twelve guarded loads (~90 SALU instructions per six updates).  LDS grows from 6 to 8 planes (61 KB
+// at S = 4): still two 1024-thread blocks per CU.
+template <int S, int TW, int TH, int NT, int DIET = 0, int MW = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 && S > 0 && !DIET ? 8 : 1, NT == 1024 && S > 0 && !DIET ? 8 : 8))) void k_df_sor_fused(DfBufs d, Geom g, float omega, int nsw)
 {
+    static_assert(!MW || (S > 0 && !DIET), "edge-weight planes: tile form only");
     constexpr int HL = 2 * S, RW = TW + 2 * HL, RH = TH + 2 * HL, HW = RW / 2, NSLOT = HW * RH, NS = (NSLOT + NT - 1) / NT;
     constexpr int PAD = S == 0 ? HW + 4 : 0;     // whole-image form: row 0 is updated, its (unused) "row above" address must stay inside LDS
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -277,7 +285,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 &
         }
         if (q < NSLOT) {
             smem[ODU + q] = vdu.x; smem[ODU + NSLOT + q] = vdu.y; smem[ODV + q] = vdv.x; smem[ODV + NSLOT + q] = vdv.y;
-            smem[OWG + q] = vw.x; smem[OWG + NSLOT + q] = vw.y;
+            if constexpr (MW) {
+                // WX at OWG (+ parity * NSLOT), WY two planes further; vw is already 0 outside the image
+                const bool dn = gy < H - 1;
+                smem[OWG + q] = gxe < W - 1 ? vw.x : 0.f; smem[OWG + NSLOT + q] = gxe + 1 < W - 1 ? vw.y : 0.f;
+                smem[OWG + 2 * NSLOT + q] = dn ? vw.x : 0.f; smem[OWG + 3 * NSLOT + q] = dn ? vw.y : 0.f;
+            } else {
+                smem[OWG + q] = vw.x; smem[OWG + NSLOT + q] = vw.y;
+            }
         }
         const int ce = (x0 + y0 + ry) & 1;                        // colour of the slot's even-x pixel
 #pragma unroll
@@ -355,6 +370,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 &
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const unsigned f = flg[c][k];
+                if constexpr (MW) {
+                    if (f & 1u) {
+                        const int q = threadIdx.x + k * NT;
+                        const int par = (f >> 6) & 1;
+                        const int A = par * NSLOT + q, Bl = (par ^ 1) * NSLOT + (par ? q : q - 1);     // self / left slot; right = left + 1
+                        const float* P = smem;
+                        const float wr = P[OWG + A], wd = P[OWG + 2 * NSLOT + A], wl = P[OWG + Bl], wu_ = P[OWG + 2 * NSLOT + A - HW];
+                        const float sigmaU = wl * P[ODU + Bl] + wr * P[ODU + Bl + 1] + wu_ * P[ODU + A - HW] + wd * P[ODU + A + HW];
+                        const float sigmaV = wl * P[ODV + Bl] + wr * P[ODV + Bl + 1] + wu_ * P[ODV + A - HW] + wd * P[ODV + A + HW];
+                        float du = P[ODU + A], dv = P[ODV + A];
+                        du += omega * ((sigmaU + b1[c][k] - dv * a12[c][k]) / a11[c][k] - du);
+                        dv += omega * ((sigmaV + b2[c][k] - du * a12[c][k]) / a22[c][k] - dv);
+                        smem[ODU + A] = du; smem[ODV + A] = dv;
+                    }
+                } else
                 if (f & 1u) {
                     const int q = threadIdx.x + k * NT;
                     const int par = (f >> 6) & 1;
