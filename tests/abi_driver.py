@@ -13,7 +13,16 @@ CPU_LIB = os.path.join(ROOT, "oracle", "libteeflow_cpu.so")
 
 
 def bind(path):
+    if os.path.abspath(path) == os.path.abspath(CPU_LIB):
+        # the checker is OpenMP code: take the oracle wrapper's precautions BEFORE libgomp initialises (passive waiting, a team
+        # no larger than the cores this process is granted -- a GPU box shows 256 hardware threads and grants 16)
+        from oracle import oracle as O
+        O.lib()
     L = C.CDLL(path)
+    if hasattr(L, "orc_set_num_threads"):
+        from oracle import oracle as O
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(min(O.effective_cpus(), 16))
     vp, i32, f32, dbl = C.c_void_p, C.c_int, C.c_float, C.c_double
     L.tf_abi_version.restype = i32
     L.tf_default_params.argtypes = [C.POINTER(_lib.TfParams)]

@@ -162,13 +162,36 @@ __device__ __forceinline__ double err_v(const float* u1n, const float* u1k, cons
     return 0.0;
 }
 
-template <int HYP, int DIV, int ERR, int WAVES>
+// LAYOUT 0: 15 separate planes (what the engine has).  LAYOUT 1: the planes of a group share a row -- constants {wx, wy, rho},
+// flow {u1, u2}, dual {p11..p22} on the read side, flow / dual on the write side: 5 streams instead of 15.  LAYOUT 2: all 9 input
+// planes of a row contiguous, all 6 output planes contiguous: 2 streams.  Same bytes, same arithmetic.
+template <int LAYOUT>
+__device__ __forceinline__ size_t in_off(int k, size_t rowidx, int pitch, size_t plane, int x)
+{
+    // k: 0 u1, 1 u2, 2 wx, 3 wy, 4 rho, 5..8 p
+    if (LAYOUT == 0) return (size_t)k * plane + rowidx * pitch + x;
+    if (LAYOUT == 2) return (rowidx * 9 + k) * pitch + x;
+    if (k < 2) return (rowidx * 2 + k) * pitch + x;                                   // flow group at plane 0..1
+    if (k < 5) return 2 * plane + (rowidx * 3 + (k - 2)) * pitch + x;                 // constants at plane 2..4
+    return 5 * plane + (rowidx * 4 + (k - 5)) * pitch + x;                            // dual at plane 5..8
+}
+template <int LAYOUT>
+__device__ __forceinline__ size_t out_off(int k, size_t rowidx, int pitch, size_t plane, int x)
+{
+    // k: 0 u1, 1 u2, 2..5 p
+    if (LAYOUT == 0) return (size_t)k * plane + rowidx * pitch + x;
+    if (LAYOUT == 2) return (rowidx * 6 + k) * pitch + x;
+    if (k < 2) return (rowidx * 2 + k) * pitch + x;
+    return 2 * plane + (rowidx * 4 + (k - 2)) * pitch + x;
+}
+
+template <int HYP, int DIV, int ERR, int WAVES, int LAYOUT = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void k_ab(const float* __restrict__ in, float* __restrict__ out, int rows, int pitch, size_t plane, float l_t, float theta, float taut,
           unsigned long long* __restrict__ err, int wrap)
 {
     const int lane = threadIdx.x, x = lane * 4;
-    const size_t base = (size_t)blockIdx.x * rows * pitch;
+    const size_t base = (size_t)blockIdx.x * rows;
     float pu1[4] = {0, 0, 0, 0}, pu2[4] = {0, 0, 0, 0}, pp12[4] = {0, 0, 0, 0}, pp22[4] = {0, 0, 0, 0};
     double accA = 0.0, accB = 0.0;
     unsigned inw[5];
@@ -176,18 +199,18 @@ void k_ab(const float* __restrict__ in, float* __restrict__ out, int rows, int p
     for (int j = 0; j < 5; ++j) inw[j] = opaque_u(~0u);
     const unsigned keep[4] = {inw[0], inw[1], inw[2], inw[3]};
     for (int r = 0; r < rows; ++r) {
-        const size_t row = base + (size_t)(r & wrap) * pitch + x;
+        const size_t ri = base + (size_t)(r & wrap);
         QuadU qu;
         float4 v;
-        v = ld4(in + 0 * plane + row); UNPACK4(qu.u1k, v)
-        v = ld4(in + 1 * plane + row); UNPACK4(qu.u2k, v)
-        v = ld4(in + 2 * plane + row); UNPACK4(qu.wx, v)
-        v = ld4(in + 3 * plane + row); UNPACK4(qu.wy, v)
-        v = ld4(in + 4 * plane + row); UNPACK4(qu.r, v)
-        v = ld4(in + 5 * plane + row); UNPACK4(qu.p11, v)
-        v = ld4(in + 6 * plane + row); UNPACK4(qu.p12, v)
-        v = ld4(in + 7 * plane + row); UNPACK4(qu.p21, v)
-        v = ld4(in + 8 * plane + row); UNPACK4(qu.p22, v)
+        v = ld4(in + in_off<LAYOUT>(0, ri, pitch, plane, x)); UNPACK4(qu.u1k, v)
+        v = ld4(in + in_off<LAYOUT>(1, ri, pitch, plane, x)); UNPACK4(qu.u2k, v)
+        v = ld4(in + in_off<LAYOUT>(2, ri, pitch, plane, x)); UNPACK4(qu.wx, v)
+        v = ld4(in + in_off<LAYOUT>(3, ri, pitch, plane, x)); UNPACK4(qu.wy, v)
+        v = ld4(in + in_off<LAYOUT>(4, ri, pitch, plane, x)); UNPACK4(qu.r, v)
+        v = ld4(in + in_off<LAYOUT>(5, ri, pitch, plane, x)); UNPACK4(qu.p11, v)
+        v = ld4(in + in_off<LAYOUT>(6, ri, pitch, plane, x)); UNPACK4(qu.p12, v)
+        v = ld4(in + in_off<LAYOUT>(7, ri, pitch, plane, x)); UNPACK4(qu.p21, v)
+        v = ld4(in + in_off<LAYOUT>(8, ri, pitch, plane, x)); UNPACK4(qu.p22, v)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { qu.p12u[i] = pp12[i]; qu.p22u[i] = pp22[i]; }
         qu.l11 = __shfl_up(qu.p11[3], 1, 64); qu.l21 = __shfl_up(qu.p21[3], 1, 64);
@@ -220,9 +243,9 @@ void k_ab(const float* __restrict__ in, float* __restrict__ out, int rows, int p
             uy1[i] = mask_f(u1b[i] - pu1[i], inw[0]); uy2[i] = mask_f(u2b[i] - pu2[i], inw[0]);
         }
         p_quad_v<HYP, DIV>(taut, ux1, uy1, ux2, uy2, q11, q12, q21, q22, s11, s12, s21, s22);
-        st4(out + 0 * plane + row, PACK4(u1b)); st4(out + 1 * plane + row, PACK4(u2b));
-        st4(out + 2 * plane + row, PACK4(s11)); st4(out + 3 * plane + row, PACK4(s12));
-        st4(out + 4 * plane + row, PACK4(s21)); st4(out + 5 * plane + row, PACK4(s22));
+        st4(out + out_off<LAYOUT>(0, ri, pitch, plane, x), PACK4(u1b)); st4(out + out_off<LAYOUT>(1, ri, pitch, plane, x), PACK4(u2b));
+        st4(out + out_off<LAYOUT>(2, ri, pitch, plane, x), PACK4(s11)); st4(out + out_off<LAYOUT>(3, ri, pitch, plane, x), PACK4(s12));
+        st4(out + out_off<LAYOUT>(4, ri, pitch, plane, x), PACK4(s21)); st4(out + out_off<LAYOUT>(5, ri, pitch, plane, x), PACK4(s22));
 #pragma unroll
         for (int i = 0; i < 4; ++i) { pu1[i] = u1b[i]; pu2[i] = u2b[i]; pp12[i] = s12[i]; pp22[i] = s22[i]; }
     }
@@ -277,16 +300,16 @@ __global__ void k_check(unsigned long long* out /* [6]: n, zone2, bad2, zone3, b
     atomicAdd(&out[0], n); atomicAdd(&out[1], z2); atomicAdd(&out[2], b2); atomicAdd(&out[3], z3); atomicAdd(&out[4], b3); atomicAdd(&out[5], wz2);
 }
 
-template <int HYP, int DIV, int ERR, int WAVES>
+template <int HYP, int DIV, int ERR, int WAVES, int LAYOUT = 0>
 static double run(const char* name, const float* in, float* out, int rows, int pitch, size_t plane, unsigned long long* err, int cus, int wrap)
 {
     const int waves_total = cus * 4 * WAVES;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k_ab<HYP, DIV, ERR, WAVES>), dim3(waves_total), dim3(64), 0, 0, in, out, 4, pitch, plane, 0.045f, 0.3f, 0.8333f, err, wrap);
+    hipLaunchKernelGGL((k_ab<HYP, DIV, ERR, WAVES, LAYOUT>), dim3(waves_total), dim3(64), 0, 0, in, out, 4, pitch, plane, 0.045f, 0.3f, 0.8333f, err, wrap);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k_ab<HYP, DIV, ERR, WAVES>), dim3(waves_total), dim3(64), 0, 0, in, out, rows, pitch, plane, 0.045f, 0.3f, 0.8333f, err, wrap);
+        hipLaunchKernelGGL((k_ab<HYP, DIV, ERR, WAVES, LAYOUT>), dim3(waves_total), dim3(64), 0, 0, in, out, rows, pitch, plane, 0.045f, 0.3f, 0.8333f, err, wrap);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -319,6 +342,13 @@ int main()
         printf("  in-context cost per px-iteration (SIMD cycles): 2 hypots %.1f, 5 divisions %.1f, error term %.1f, rest %.1f; candidates save %.1f / %.1f\n",
                (base - nh) / 512, (base - nd) / 512, (base - ne) / 512, fl / 512, (base - c2) / 512, (base - c3) / 512);
     }
+    // memory layout of the 15 planes, same bytes and arithmetic (streaming): does the number of concurrent streams limit the HBM rate?
+    run<0, 0, 0, 3, 0>("LAYOUT 15 separate planes, shipped arithmetic", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
+    run<0, 0, 0, 3, 1>("LAYOUT 5 row-interleaved groups", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
+    run<0, 0, 0, 3, 2>("LAYOUT 2 streams (9 in / 6 out interleaved)", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
+    run<1, 1, 1, 3, 0>("LAYOUT 15 planes, cheap arithmetic", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
+    run<1, 1, 1, 3, 1>("LAYOUT 5 groups, cheap arithmetic", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
+    run<1, 1, 1, 3, 2>("LAYOUT 2 streams, cheap arithmetic", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
     run<0, 0, 0, 2>("shipped arithmetic", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
     run<2, 0, 0, 2>("CANDIDATE f32 seed", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
     run<0, 0, 0, 1>("shipped arithmetic", in, out, rows, pitch, plane, err, cus, 0x7fffffff);
