@@ -4,7 +4,7 @@
   <tag>_bench_pmc.json                                      the line of `bench.py --pmc` (roofline.traffic measured in that run)
   hbm_traffic.json                                          FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels, tagged with the kernel source fingerprint
   <tag>_sq_counters.json                                    SQ / GRBM counters of k_iter2_rows and k_df_sor_fused: totals, per-launch means, derived shares
-usage: python tools/collect_profiles.py r02"""
+usage: python tools/collect_profiles.py r02 [destination directory, default profiles/]"""
 import collections
 import csv
 import glob
@@ -78,7 +78,11 @@ def sq_summary(tag, algo, kernel):
 
 
 def main():
+    global DST
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    if len(sys.argv) > 2:                       # on the GPU box: condense into a small directory under gpurun_out/ (profiles/ does not travel back)
+        DST = sys.argv[2]
+        os.makedirs(DST, exist_ok=True)
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     for name in ("default", "lanes1"):
         st = glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True)

@@ -27,3 +27,7 @@ timeout -k 10 200 python3 tools/launch_profile.py --batch 64 > $OUT/${TAG}_launc
 [ -x tools/microbench/ablate_probe ] && (cd tools/microbench && timeout -k 10 200 ./ablate_probe > $OUT/${TAG}_ablate_probe.txt 2>&1; echo "ablate rc=$?")
 bash tools/pmc_sq.sh $TAG TVL1 > $OUT/pmc_sq_tvl1.log 2>&1; tail -2 $OUT/pmc_sq_tvl1.log
 bash tools/pmc_sq.sh $TAG deepflow > $OUT/pmc_sq_df.log 2>&1; tail -2 $OUT/pmc_sq_df.log
+# condense on the box (the raw kernel traces and counter CSVs are tens of MB; gpurun carries at most 64 MiB back) and drop the raw files
+python3 tools/collect_profiles.py $TAG $GRAFT_REPO_ROOT/gpurun_out/collected_$TAG > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
+rm -rf $OUT/default $OUT/lanes1 $OUT/pmc_live/pmc_live_* $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_TVL1/sq? $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_deepflow/sq?
+du -sh $GRAFT_REPO_ROOT/gpurun_out
