@@ -13,13 +13,10 @@ CPU_LIB = os.path.join(ROOT, "oracle", "libteeflow_cpu.so")
 
 
 def bind(path):
-    if os.path.abspath(path) == os.path.abspath(CPU_LIB):
-        # the checker is OpenMP code: take the oracle wrapper's precautions BEFORE libgomp initialises (passive waiting, a team
-        # no larger than the cores this process is granted -- a GPU box shows 256 hardware threads and grants 16)
-        from oracle import oracle as O
-        O.lib()
     L = C.CDLL(path)
     if hasattr(L, "orc_set_num_threads"):
+        # the checker is OpenMP code: before its first parallel region, a team no larger than the cores this process is
+        # granted (a GPU box shows 256 hardware threads and grants 16 -- a default-sized team spins for minutes there)
         from oracle import oracle as O
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(min(O.effective_cpus(), 16))
