@@ -80,3 +80,41 @@ def test_config5_with_stand_in_segmentor_on_gpu():
     for i in range(5):
         f = raw[i] / cf                                                   # the engine's pixel flow (scale is applied last)
         assert np.array_equal(out[i], (f - wase_background(f, mask)) * cf)
+
+
+def test_config5_full_chain_256_n32():
+    """BASELINE.json configs[4] end to end at the size BASELINE.md section 3 names (synthetic study, N = 32, 256 x 256, seed 1000):
+    stand-in segmentor -> masks -> device frame conditioning + DualTVL1 (one batched call) -> pad + unit scale -> the float16
+    the HDF5 file stores -> radial / longitudinal projection + per-frame percentiles on the device, against the host (numpy)
+    restatement of the reference's analysis."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd import analysis as A, masks
+    from tee_optical_flow_amd.pipeline import process_video
+    from tee_optical_flow_amd.synth import speckle_sequence
+    from tests.test_study_driver_cpu import _FakeSam
+    N, H, W = 32, 256, 256
+    g = speckle_sequence(1000, N, H, W)
+    nparr = np.repeat(g[..., None], 3, axis=3)
+    md = {"pixel_spacing": 0.05, "frame_rate": 40.0, "R_wave_data_present": False, "R_times": None}
+    sam = _FakeSam()
+    flow = process_video(None, None, sam, verbose=False, mode="RVIO_2class", bkgd_comp="none", no_saliency=True, nparr=nparr, metadata=md)
+    assert flow.shape == (N, H, W, 2) and flow.dtype == np.float32 and np.array_equal(flow[-1], flow[-2])
+    # the solver really ran on every pair: a study of a moving texture has motion everywhere
+    assert (np.abs(flow[:-1]).reshape(N - 1, -1).max(axis=1) > 0.5).all()
+    stored = flow.astype(np.float16).astype(np.float32)                  # what OpticalFlowDataset reads back (optical_flow_dataset.py:57)
+    av = masks.predict_movie(nparr, sam, mode="RVIO_2class")["av"][..., 0]
+    cent = []
+    for i in range(N):
+        ys, xs = np.nonzero(av[i])
+        cent.append((float(ys.mean()), float(xs.mean())) if len(ys) else (H / 2.0, W / 2.0))
+    eng = T.DenseFlow(device_id=0)
+    try:
+        dev = A.radlong_stats_device(eng, stored, cent, return_arrays=True)
+    finally:
+        eng.close()
+    rad, lon = A.calculate_comp_magnitude(stored, cent)
+    assert np.array_equal(dev["rad_arr"], rad) and np.array_equal(dev["long_arr"], lon)
+    for key, arr in (("radial", rad), ("longitudinal", lon)):
+        f, e, hi, lo = A.calc_bidirectional_hist(arr, N)
+        df, de, dhi, dlo = dev[key]
+        assert np.array_equal(df, f) and np.array_equal(de, np.asarray(e)[:-1]) and np.array_equal(dhi, hi) and np.array_equal(dlo, lo)
