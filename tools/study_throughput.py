@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Row f3 as a measurement: studies per second through process_folder (reference calculate_optical_flow.py:243-290) on the
+GPU box, HDF5 writing included, with the writer thread beside the next solve and without it.  h5py lives in the image's
+second interpreter, so run it there:
+    LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 /opt/conda/bin/python3.9 tools/study_throughput.py [--studies 6] [--frames 65] [--size 512]"""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--studies", type=int, default=6)
+    ap.add_argument("--frames", type=int, default=65)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--algo", default="TVL1")
+    a = ap.parse_args()
+    from tee_optical_flow_amd import pipeline as P
+    from tee_optical_flow_amd import hdf5_out
+    from tee_optical_flow_amd.synth import speckle_sequence
+    tmp = tempfile.mkdtemp(prefix="teeflow_studies_")
+    src = os.path.join(tmp, "in")
+    os.makedirs(src)
+    for k in range(a.studies):
+        g = speckle_sequence(500 + k, a.frames, a.size, a.size)
+        np.savez(os.path.join(src, f"study{k:02d}.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.04, frame_rate=50.0, patient_id=f"S{k}")
+    model = P.make_flow_model(a.algo)
+    kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo=a.algo, flow_model=model)
+    P.process_folder(src, os.path.join(tmp, "warm"), None, process_subset=True, file_subset_list=["study00.npz"], **kw)   # warm-up: allocations, masks code paths
+    t0 = time.perf_counter()
+    errs = P.process_folder(src, os.path.join(tmp, "overlapped"), None, **kw)
+    t_overlap = time.perf_counter() - t0
+    # the same walk with the HDF5 write done in line (what the reference does): time the writer by making defer synchronous
+    real = hdf5_out.save_optical_flow_to_hdf5
+    t_write = [0.0]
+
+    def timed(*args, **kwargs):
+        t = time.perf_counter(); real(*args, **kwargs); t_write[0] += time.perf_counter() - t
+    hdf5_out.save_optical_flow_to_hdf5 = timed
+    orig_pf = P.process_folder
+
+    def serial_folder(*args, **kwargs):
+        # no writer thread: process_video writes before it returns
+        files = sorted(os.listdir(args[0]))
+        os.makedirs(args[1], exist_ok=True)
+        for f in files:
+            nparr, md, pid, hr = P.read_study(os.path.join(args[0], f))
+            P.process_video(None, os.path.join(args[1], f[:-4] + ".hdf5"), None, verbose=False, mode="otsu", no_saliency=True, OF_algo=a.algo,
+                            nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, flow_model=model)
+    t0 = time.perf_counter()
+    serial_folder(src, os.path.join(tmp, "serial"))
+    t_serial = time.perf_counter() - t0
+    hdf5_out.save_optical_flow_to_hdf5 = real
+    model.close()
+    sz = sum(os.path.getsize(os.path.join(tmp, "overlapped", f)) for f in os.listdir(os.path.join(tmp, "overlapped"))) / a.studies / 1e6
+    print(f"{a.algo}: {a.studies} studies of {a.frames} frames {a.size}x{a.size} (errors: {errs})")
+    print(f"  writer thread beside the next solve: {t_overlap:6.2f} s = {t_overlap / a.studies * 1e3:7.1f} ms per study, {a.studies * (a.frames - 1) / t_overlap:7.1f} pairs/s end to end")
+    print(f"  write in line (reference order)    : {t_serial:6.2f} s = {t_serial / a.studies * 1e3:7.1f} ms per study, of which HDF5 gzip-9 write {t_write[0] / a.studies * 1e3:7.1f} ms; file {sz:.1f} MB per study")
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
