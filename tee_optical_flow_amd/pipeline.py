@@ -90,6 +90,16 @@ def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conver
     return flows * conversion_factor                              # (:600)
 
 
+def _prep_frames(nparr, flipLR):
+    """Reference :533-548: greyscale stacks become RGB, optional left-right flip."""
+    nparr = np.asarray(nparr)
+    if nparr.ndim == 3 and nparr.shape[0] > 1:
+        nparr = np.repeat(nparr[..., None], 3, axis=3)
+    if flipLR:
+        nparr = np.flip(nparr, axis=2)
+    return nparr
+
+
 def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode="A4C", bkgd_comp="none", flipLR=False,
                   no_saliency=False, OF_algo="TVL1", save_mask_subset=None, include_waveforms=False, waveform_folder=None,
                   config=None, *, nparr=None, metadata=None, patient_id="", heart_rate=0, waveforms=None, flow_model=None,
@@ -112,12 +122,9 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
     nparr = np.asarray(nparr)
     if metadata is None:
         metadata = {"pixel_spacing": None, "frame_rate": None, "R_wave_data_present": False, "R_times": None}
-    if nparr.ndim == 3 and nparr.shape[0] > 1:
-        nparr = np.repeat(nparr[..., None], 3, axis=3)
+    nparr = _prep_frames(nparr, flipLR)
     ps, fr = metadata["pixel_spacing"], metadata["frame_rate"]
     conversion_factor = 1.0 if ps is None or fr is None else ps * fr
-    if flipLR:
-        nparr = np.flip(nparr, axis=2)
     if mask_dict is None:
         if mode == "otsu":
             from .masks import predict_movie_thres
@@ -195,7 +202,8 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
       * like the reference, `pixel_spacing` / `frame_rate` are accepted and ignored, and `config` is not forwarded unless given.
     Beyond the reference: the slice is dealt round-robin over `world` ranks (one process per GPU, rank r takes files
     r, r+world, ...: no exchange is needed, studies are independent), one flow model serves all studies of the call, and
-    a writer thread deflates/writes study k while study k+1 is being solved.  Returns the list of (filename, error string)."""
+    the walk is a three-stage pipeline: a reader thread loads study k+1 (and computes its Otsu masks), the caller's thread
+    solves study k on the GPU, a writer thread deflates/writes study k-1.  Returns the list of (filename, error string)."""
     os.makedirs(save_folder, exist_ok=True)
     file_list = sorted(os.listdir(dcm_folder))                      # os.listdir order is arbitrary; sorted = same slices on every rank
     errors = []
@@ -212,7 +220,19 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     own = flow_model is None
     model = None
     writer = ThreadPoolExecutor(1)
+    reader_pool = ThreadPoolExecutor(1)
     pending = []
+
+    def prepare(filename):
+        """Read the study and -- for the Otsu mode, which is pure numpy/scipy -- compute its masks, one study ahead of the
+        GPU: with the solver at milliseconds per pair, this host work and the gzip-9 write are what a study costs."""
+        nparr, md, pid, hr = reader(os.path.join(dcm_folder, filename))
+        masks_ahead = None
+        if mode == "otsu":
+            from .masks import predict_movie_thres
+            masks_ahead = predict_movie_thres(_prep_frames(nparr, flipLR), verbose=False,
+                                              config=config if config is not None else default_optical_flow_config())
+        return nparr, md, pid, hr, masks_ahead
 
     def defer(job):
         from .hdf5_out import save_optical_flow_to_hdf5
@@ -228,6 +248,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 errors.append((os.path.basename(path), f"{type(e).__name__}: {e}"))
 
     try:
+        todo = []
         for filename in mine:
             stem, ext = os.path.splitext(filename)
             save_path = os.path.join(save_folder, stem + ".hdf5")
@@ -238,10 +259,14 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
             if ext.lower().lstrip(".") not in extensions:
                 logger.warning(f"File extension must be one of {extensions}, found {ext}, skipping")
                 continue
+            todo.append((filename, stem, save_path))
+        ahead = reader_pool.submit(prepare, todo[0][0]) if todo else None
+        for k, (filename, stem, save_path) in enumerate(todo):
             if verbose:
                 logger.info(f"Processing file: {filename}...")
+            mine_fut, ahead = ahead, (reader_pool.submit(prepare, todo[k + 1][0]) if k + 1 < len(todo) else None)
             try:
-                nparr, md, pid, hr = reader(os.path.join(dcm_folder, filename))
+                nparr, md, pid, hr, masks_ahead = mine_fut.result()
                 if model is None:
                     model = flow_model if flow_model is not None else make_flow_model(OF_algo, config, device_id)
                 waveforms = None
@@ -251,7 +276,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                               bkgd_comp=bkgd_comp, flipLR=flipLR, no_saliency=no_saliency, OF_algo=OF_algo,
                               save_mask_subset=save_mask_subset, include_waveforms=include_waveforms, waveform_folder=waveform_folder,
                               config=config, nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, waveforms=waveforms,
-                              flow_model=model, _defer_save=defer)
+                              flow_model=model, mask_dict=masks_ahead, _defer_save=defer)
             except Exception as e:
                 logger.error(f"Error processing {filename}: {e}")
                 if verbose:
@@ -261,6 +286,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
         reap(block=True)
     finally:
         writer.shutdown(wait=True)
+        reader_pool.shutdown(wait=True)
         if own and model is not None:
             model.close()
     return errors
