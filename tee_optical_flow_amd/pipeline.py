@@ -239,7 +239,8 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
         pending.append((job[0], writer.submit(save_optical_flow_to_hdf5, *job)))
 
     def reap(block):
-        while pending and (block or pending[0][1].done()):
+        # at most two studies wait for the writer: a faster solver must not pile finished studies up in host memory
+        while pending and (block or len(pending) > 2 or pending[0][1].done()):
             path, fut = pending.pop(0)
             try:
                 fut.result()
