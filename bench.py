@@ -388,6 +388,9 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                 "measured_on": f"{steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
         rate = units_per_launch / secs if secs else None
         if algo == "TVL1":
+            # algorithmic (compulsory) bytes of the kernel that is actually launched: 9 plane reads + 6 writes once per TWO iterations
+            roof["algorithmic_GBps_30B"] = rate * 30.0 / 1e9 if rate else None
+            roof["algorithmic_bytes_per_launch_30B"] = units_per_launch * 30.0
             roof["notional_GBps_60B"] = rate * 60.0 / 1e9 if rate else None     # one-iteration-per-pass kernel's compulsory traffic
             roof["notional_GBps_88B"] = rate * 88.0 / 1e9 if rate else None     # two-kernel K_A/K_B formulation
             roof["notional_note"] = ("what kernels that make one HBM pass per inner iteration would have had to move at this rate; the shipped kernel "
