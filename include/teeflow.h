@@ -141,6 +141,12 @@ int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float 
 /* B independent pairs (BASELINE.json config 3): I0s, I1s host uint8 [B][H][W]; flow_out float32 [B][H][W][2]. */
 int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st);
 
+/* CV_32FC1 frames: cv2's DualTVL1 accepts float32 images with values in [0,1] and multiplies them by 255 when it builds
+ * level 0 (the reference itself always hands over uint8, calculate_optical_flow.py:588).  Host pointers, DualTVL1 handles
+ * only (TF_ERR_UNSUPPORTED for DeepFlow); otherwise identical to tf_calc_pair / tf_calc_pairs. */
+int tf_calc_pair_f32(tf_handle* h, const float* I0, const float* I1, int H, int W, float* flow_out, tf_stats* st);
+int tf_calc_pairs_f32(tf_handle* h, const float* I0s, const float* I1s, int B, int H, int W, float* flow_out, tf_stats* st);
+
 /* Same, with every buffer already resident in this device's HBM (pointers are device pointers); work is
  * enqueued on the handle's stream and the call returns after the stream has drained. */
 int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W,

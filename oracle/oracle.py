@@ -85,6 +85,8 @@ def lib():
                                   C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_tvl1_calc.argtypes = [C.POINTER(OrcParams), u8p, u8p, C.c_int, C.c_int, fp, C.c_void_p]
         L.orc_tvl1_calc.restype = C.c_int
+        L.orc_tvl1_calc_f32.argtypes = [C.POINTER(OrcParams), fp, fp, C.c_int, C.c_int, fp, C.c_void_p]
+        L.orc_tvl1_calc_f32.restype = C.c_int
         L.orc_pyramid_level.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_set_num_threads(min(effective_cpus(), 16))
@@ -181,15 +183,19 @@ def iterate(I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p22, nsteps, lam=0.1
 
 
 def tvl1_calc(I0, I1, params=None, return_iters=False):
-    """Full DualTVL1 on one uint8 pair -> float32 [H,W,2]."""
-    I0 = np.ascontiguousarray(I0, dtype=np.uint8)
-    I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+    """Full DualTVL1 on one uint8 (or float32 in [0,1], CV_32FC1) pair -> float32 [H,W,2]."""
+    f32 = np.asarray(I0).dtype == np.float32
+    I0 = np.ascontiguousarray(I0, dtype=np.float32 if f32 else np.uint8)
+    I1 = np.ascontiguousarray(I1, dtype=np.float32 if f32 else np.uint8)
     assert I0.shape == I1.shape and I0.ndim == 2
     p = params if params is not None else default_params()
     h, w = I0.shape
     flow = np.empty((h, w, 2), np.float32)
     iters = np.zeros((p.nscales, max(p.warps, 1), 2), np.int32)
-    rc = lib().orc_tvl1_calc(C.byref(p), I0, I1, h, w, flow.reshape(-1), iters.ctypes.data_as(C.c_void_p))
+    if f32:
+        rc = lib().orc_tvl1_calc_f32(C.byref(p), I0.reshape(-1), I1.reshape(-1), h, w, flow.reshape(-1), iters.ctypes.data_as(C.c_void_p))
+    else:
+        rc = lib().orc_tvl1_calc(C.byref(p), I0, I1, h, w, flow.reshape(-1), iters.ctypes.data_as(C.c_void_p))
     if rc <= 0:
         raise RuntimeError(f"orc_tvl1_calc failed rc={rc}")
     if return_iters:

@@ -516,10 +516,10 @@ static void proc_one_scale(const orc_params* P, const float* I0, const float* I1
 /* Entry point.  I0/I1: uint8 [H][W]; flow: float32 [H][W][2] (x then y displacement, pixels/frame).
  * iters (optional): int32 [nscales][warps][2] = (inner iterations, outer iterations) executed, level 0 first.
  * returns the number of pyramid levels actually used (>0), or a negative error code. */
-ORC_API int orc_tvl1_calc(const orc_params* P, const uint8_t* I0u8, const uint8_t* I1u8, int H, int W,
-                          float* flow, int* iters)
+static int tvl1_core(const orc_params* P, const uint8_t* I0u8, const uint8_t* I1u8, const float* I0f, const float* I1f,
+                     int H, int W, float* flow, int* iters)
 {
-    if (!P || !I0u8 || !I1u8 || !flow || H <= 0 || W <= 0) return -1;
+    if (!P || !(I0u8 || I0f) || !(I1u8 || I1f) || !flow || H <= 0 || W <= 0) return -1;
     if (P->nscales < 1 || P->nscales > 64 || P->warps < 0 || P->use_initial_flow) return -2;
     if (P->median_filtering != 1 && P->median_filtering != 3 && P->median_filtering != 5) return -3;
     int nscales = P->nscales;
@@ -531,7 +531,9 @@ ORC_API int orc_tvl1_calc(const orc_params* P, const uint8_t* I0u8, const uint8_
     const size_t n0 = (size_t)W * H;
     ws[0] = W; hs[0] = H;
     I0s[0] = (float*)malloc(n0 * 4); I1s[0] = (float*)malloc(n0 * 4);
-    for (size_t i = 0; i < n0; ++i) { I0s[0][i] = (float)I0u8[i]; I1s[0][i] = (float)I1u8[i]; } /* convertTo(.., 1.0) */
+    if (I0u8) for (size_t i = 0; i < n0; ++i) { I0s[0][i] = (float)I0u8[i]; I1s[0][i] = (float)I1u8[i]; } /* convertTo(.., 1.0) */
+    /* CV_32F input: convertTo(.., 255.0) = src * 255 + 0 in fp32 (an fma with a zero addend rounds like the multiply) */
+    else for (size_t i = 0; i < n0; ++i) { I0s[0][i] = I0f[i] * 255.0f; I1s[0][i] = I1f[i] * 255.0f; }
     u1s[0] = (float*)malloc(n0 * 4); u2s[0] = (float*)malloc(n0 * 4);
     if (use_gamma) u3s[0] = (float*)malloc(n0 * 4);
     for (int s = 1; s < nscales; ++s) {
@@ -578,6 +580,19 @@ ORC_API int orc_tvl1_calc(const orc_params* P, const uint8_t* I0u8, const uint8_
     for (int s = 0; s < 64; ++s) { free(I0s[s]); free(I1s[s]); free(u1s[s]); free(u2s[s]); free(u3s[s]); }
     free(n_in); free(n_out);
     return nscales;
+}
+
+ORC_API int orc_tvl1_calc(const orc_params* P, const uint8_t* I0u8, const uint8_t* I1u8, int H, int W,
+                          float* flow, int* iters)
+{
+    return tvl1_core(P, I0u8, I1u8, NULL, NULL, H, W, flow, iters);
+}
+
+/* Same for CV_32FC1 frames (cv2 accepts them with values in [0,1]; the reference itself always hands over uint8,
+ * calculate_optical_flow.py:588). */
+ORC_API int orc_tvl1_calc_f32(const orc_params* P, const float* I0, const float* I1, int H, int W, float* flow, int* iters)
+{
+    return tvl1_core(P, NULL, NULL, I0, I1, H, W, flow, iters);
 }
 
 /* Pyramid only (for kernel-level parity tests): writes level s (>=1) of the x0.8 pyramid of a u8 image */

@@ -71,6 +71,7 @@ struct tf_handle {
     hipStream_t copy_stream = nullptr;           // D2H of finished sub-batches overlaps the next solve (pinned destinations)
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};   // solve done [2], copy done [2]
     uint8_t* st_u8 = nullptr; size_t st_u8_bytes = 0;
+    int src_f32 = 0;                       // this call's frames are float32 in [0,1] (tf_calc_pairs_f32): 4 bytes per pixel
     float* st_flow = nullptr; size_t st_flow_bytes = 0;
     hipEvent_t ev[4] = {};
     // profiling of tvl1_iter launches
@@ -567,7 +568,8 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
     const tf_params& P = h->P;
     hipStream_t s = h->stream;
     const Geom g0 = h->lv[0];
-    hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
+    if (h->src_f32) hipLaunchKernelGGL(k_f32_to_level0, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, (const float*)dframes, h->pyr[0], g0);
+    else hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
     for (int l = 1; l < h->nlev; ++l) {
         const double sc = 1.0 / P.scale_step;   // resize(src, Size(), fx, fy): scale = 1/fx
         hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc);
@@ -612,7 +614,8 @@ int solve_resident_sched(tf_handle* h, const uint8_t* dframes, int F, int B, int
     hipStream_t s = h->stream;
     const Geom g0 = h->lv[0];
     const int total = P.inner_iterations * P.outer_iterations;
-    hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
+    if (h->src_f32) hipLaunchKernelGGL(k_f32_to_level0, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, (const float*)dframes, h->pyr[0], g0);
+    else hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
     for (int l = 1; l < h->nlev; ++l) {
         const double sc = 1.0 / P.scale_step;
         hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc);
@@ -1003,7 +1006,9 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     rc = deep ? df_ensure_alloc(h, H, W, n_pairs) : ensure_alloc(h, H, W, n_pairs);
     if (rc) return rc;
     if (deep) h->cap = h->dcap;
-    const size_t fpx = (size_t)H * W;
+    if (deep && h->src_f32) return fail(h, TF_ERR_UNSUPPORTED, "float32 frames are supported by the DualTVL1 engine only");
+    const size_t fpx = (size_t)H * W * (h->src_f32 ? 4 : 1);   // BYTES per frame (the flow offsets below use npx)
+    const size_t npx = (size_t)H * W;
     h->last_iters.assign(deep ? 0 : (size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
     h->last_pairs = n_pairs; h->last_nlev = deep ? h->dnlev : h->nlev; h->last_warps = deep ? 0 : h->P.warps;
     h->iter_launches = 0; h->prof_used = 0; h->df_sor_bytes = 0;
@@ -1027,7 +1032,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         HIPC(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
         for (auto& e : h->cev) HIPC(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const size_t flow_half = (size_t)step * fpx * 2;          // floats per staging half
+    const size_t flow_half = (size_t)step * npx * 2;          // floats per staging half
     if (!device) {
         rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, (overlap ? 2 : 1) * flow_half * sizeof(float));
         if (rc) return rc;
@@ -1053,7 +1058,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
                 dfr = h->st_u8;
             }
         }
-        dfl = device ? flow_out + (size_t)c0 * fpx * 2 : h->st_flow + (overlap ? (size_t)(kb & 1) * flow_half : 0);
+        dfl = device ? flow_out + (size_t)c0 * npx * 2 : h->st_flow + (overlap ? (size_t)(kb & 1) * flow_half : 0);
         if (overlap && kb >= 2) HIPC(h, hipStreamWaitEvent(h->stream, h->cev[2 + (kb & 1)], 0));   // that half's last copy-out
         HIPC(h, hipEventRecord(h->ev[1], h->stream));
         rc = deep ? df_solve_resident(h, dfr, F, nb, off0, off1, scale, dfl)
@@ -1063,10 +1068,10 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         if (overlap) {
             HIPC(h, hipEventRecord(h->cev[kb & 1], h->stream));
             HIPC(h, hipStreamWaitEvent(h->copy_stream, h->cev[kb & 1], 0));
-            HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * fpx * 2, dfl, (size_t)nb * fpx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
+            HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * npx * 2, dfl, (size_t)nb * npx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
             HIPC(h, hipEventRecord(h->cev[2 + (kb & 1)], h->copy_stream));
         } else if (!device)
-            HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * fpx * 2, h->st_flow, (size_t)nb * fpx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * npx * 2, h->st_flow, (size_t)nb * npx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         if (!deep)
             HIPC(h, hipMemcpyAsync(h->last_iters.data() + (size_t)c0 * h->nlev * h->P.warps * 2, h->iters_dev,
                                    (size_t)nb * h->nlev * h->P.warps * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1141,14 +1146,14 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->is_twin = true;
         h->twins.push_back(t);
     }
-    const size_t fpx = (size_t)H * W;
+    const size_t npx = (size_t)H * W, fpx = npx * (h->src_f32 ? 4 : 1);      // fpx in bytes
     std::vector<tf_stats> ss((size_t)L);
     std::vector<int> rcs((size_t)L, TF_OK), first((size_t)L + 1, 0);
     for (int k = 0; k <= L; ++k) first[k] = (int)((long long)n_pairs * k / L);
     std::vector<std::thread> th;
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
-        t->P = h->P; t->DP = h->DP; t->profile = h->profile;
+        t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
@@ -1158,7 +1163,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
         const int nb = first[k + 1] - first[k];
-        float* fo = flow_out + (size_t)first[k] * fpx * 2;
+        float* fo = flow_out + (size_t)first[k] * npx * 2;
         th.emplace_back([=, &ss, &rcs] { rcs[k] = calc_common_guarded(t, mode, b0, b1, nb, H, W, scale, fo, device, &ss[k]); });
     }
     rcs[0] = calc_common_guarded(h, mode, in0, in1, first[1], H, W, scale, flow_out, device, &ss[0]);
@@ -1471,6 +1476,21 @@ TF_API int tf_calc_pair(tf_handle* h, const uint8_t* I0, const uint8_t* I1, int 
 TF_API int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st)
 {
     return calc_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, st);
+}
+
+// CV_32FC1 frames (values in [0,1]; cv2 multiplies them by 255 when it builds level 0)
+TF_API int tf_calc_pairs_f32(tf_handle* h, const float* I0s, const float* I1s, int B, int H, int W, float* flow_out, tf_stats* st)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    h->src_f32 = 1;
+    const int rc = calc_entry(h, MODE_PAIRS, (const uint8_t*)I0s, (const uint8_t*)I1s, B, H, W, 1.0f, flow_out, false, st);
+    h->src_f32 = 0;
+    return rc;
+}
+
+TF_API int tf_calc_pair_f32(tf_handle* h, const float* I0, const float* I1, int H, int W, float* flow_out, tf_stats* st)
+{
+    return tf_calc_pairs_f32(h, I0, I1, 1, H, W, flow_out, st);
 }
 
 TF_API int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, tf_stats* st)

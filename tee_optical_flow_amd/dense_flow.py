@@ -19,10 +19,10 @@ from . import _lib
 from .exceptions import OpticalFlowCalculationError
 
 
-def _u8_image_stack(a, name, ndim):
+def _u8_image_stack(a, name, ndim, allow_f32=False):
     a = np.asarray(a)
-    if a.dtype != np.uint8:
-        raise OpticalFlowCalculationError(f"{name} must be uint8 (CV_8UC1), got {a.dtype}")
+    if a.dtype != np.uint8 and not (allow_f32 and a.dtype == np.float32):
+        raise OpticalFlowCalculationError(f"{name} must be uint8 (CV_8UC1){' or float32 (CV_32FC1)' if allow_f32 else ''}, got {a.dtype}")
     if a.ndim != ndim:
         raise OpticalFlowCalculationError(f"{name} must have {ndim} dimensions, got shape {a.shape}")
     return np.ascontiguousarray(a)
@@ -180,16 +180,17 @@ class DenseFlow:
 
     # ---- cv2 protocol --------------------------------------------------------------------------
     def calc(self, I0, I1, flow=None):
-        """flow = OF_model.calc(I0, I1, None): uint8 [H,W] x2 -> float32 [H,W,2] (x, y displacement)."""
-        I0 = _u8_image_stack(I0, "I0", 2)
-        I1 = _u8_image_stack(I1, "I1", 2)
-        if I0.shape != I1.shape:
-            raise OpticalFlowCalculationError(f"I0 and I1 sizes differ: {I0.shape} vs {I1.shape}")
+        """flow = OF_model.calc(I0, I1, None): uint8 [H,W] x2 -> float32 [H,W,2] (x, y displacement).  float32 frames
+        (CV_32FC1, values in [0,1]: cv2 scales them by 255) are accepted by the DualTVL1 engine like cv2 does."""
+        I0 = _u8_image_stack(I0, "I0", 2, allow_f32=True)
+        I1 = _u8_image_stack(I1, "I1", 2, allow_f32=True)
+        if I0.shape != I1.shape or I0.dtype != I1.dtype:
+            raise OpticalFlowCalculationError(f"I0 and I1 differ: {I0.shape} {I0.dtype} vs {I1.shape} {I1.dtype}")
         H, W = I0.shape
         out = self._out((H, W, 2))
         st = _lib.TfStats()
-        _lib.check(self._L.tf_calc_pair(self._h, I0.ctypes.data, I1.ctypes.data, H, W, out.ctypes.data, C.byref(st)),
-                   self._h, "tf_calc_pair")
+        fn = self._L.tf_calc_pair_f32 if I0.dtype == np.float32 else self._L.tf_calc_pair
+        _lib.check(fn(self._h, I0.ctypes.data, I1.ctypes.data, H, W, out.ctypes.data, C.byref(st)), self._h, "tf_calc_pair")
         self._finish(st)
         return out
 
@@ -246,16 +247,16 @@ class DenseFlow:
         return flows, bg
 
     def calc_pairs(self, I0s, I1s):
-        """B independent pairs: uint8 [B,H,W] x2 -> float32 [B,H,W,2]."""
-        I0s = _u8_image_stack(I0s, "I0s", 3)
-        I1s = _u8_image_stack(I1s, "I1s", 3)
-        if I0s.shape != I1s.shape:
-            raise OpticalFlowCalculationError(f"I0s and I1s sizes differ: {I0s.shape} vs {I1s.shape}")
+        """B independent pairs: uint8 (or, DualTVL1 only, float32 in [0,1]) [B,H,W] x2 -> float32 [B,H,W,2]."""
+        I0s = _u8_image_stack(I0s, "I0s", 3, allow_f32=True)
+        I1s = _u8_image_stack(I1s, "I1s", 3, allow_f32=True)
+        if I0s.shape != I1s.shape or I0s.dtype != I1s.dtype:
+            raise OpticalFlowCalculationError(f"I0s and I1s differ: {I0s.shape} {I0s.dtype} vs {I1s.shape} {I1s.dtype}")
         B, H, W = I0s.shape
         out = self._out((B, H, W, 2))
         st = _lib.TfStats()
-        _lib.check(self._L.tf_calc_pairs(self._h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, out.ctypes.data, C.byref(st)),
-                   self._h, "tf_calc_pairs")
+        fn = self._L.tf_calc_pairs_f32 if I0s.dtype == np.float32 else self._L.tf_calc_pairs
+        _lib.check(fn(self._h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, out.ctypes.data, C.byref(st)), self._h, "tf_calc_pairs")
         self._finish(st)
         return out
 

@@ -215,7 +215,8 @@ def test_error_behaviour(engine):
     with pytest.raises(OpticalFlowCalculationError):
         engine.calc(a, np.zeros((32, 33), np.uint8), None)
     with pytest.raises(OpticalFlowCalculationError):
-        engine.calc(a.astype(np.float32), a.astype(np.float32), None)
+        engine.calc(a.astype(np.float64), a.astype(np.float64), None)     # CV_64F: cv2 rejects it too (CV_32F is accepted,
+                                                                          # tests/test_gpu_f32_input.py)
     with pytest.raises(OpticalFlowCalculationError):
         engine.setGamma(0.5)          # unsupported -> loud error, parameter unchanged
     assert engine.getGamma() == 0.0

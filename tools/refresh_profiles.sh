@@ -18,10 +18,11 @@ run_stats() {   # name, bench args...
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/${TAG}_bench_$name.json 2> $OUT/$name.err
   echo "stats $name rc=$?"
 }
-run_stats default
-run_stats lanes1 --lanes 1 --no-cpu-baseline
+# counters first: the pass rewrites profiles/hbm_traffic.json for this build, which the stats runs below then pick up
 timeout -k 10 900 python3 $GRAFT_REPO_ROOT/bench.py --pmc --pmc-dir $OUT/pmc_live --round-tag $TAG > $OUT/${TAG}_bench_pmc.json 2> $OUT/bench_pmc.err
 echo "bench --pmc rc=$?"
+run_stats default
+run_stats lanes1 --lanes 1 --no-cpu-baseline
 cd $GRAFT_REPO_ROOT
 timeout -k 10 200 python3 tools/launch_profile.py --batch 64 > $OUT/${TAG}_launch_profile_b64.txt 2>&1; echo "launch_profile rc=$?"
 [ -x tools/microbench/ablate_probe ] && (cd tools/microbench && timeout -k 10 200 ./ablate_probe > $OUT/${TAG}_ablate_probe.txt 2>&1; echo "ablate rc=$?")
