@@ -421,6 +421,56 @@ struct MedArgs {
     Geom g;
 };
 
+// Stage one 64 x 16 output tile of a plane with its halo (replicate border) in LDS.  Every load of a thread is issued
+// before its first LDS write: one memory round trip per block instead of one per 256 staged values (the staging loop used
+// to be ten dependent load -> wait -> write trips, several times the 1.5 k cycles the selection network takes).  Tiles
+// whose 64 columns lie inside the image take float4 loads for the body and scalar loads for the 2R halo columns.
+template <int KS>
+__device__ __forceinline__ void median_stage(float (*t)[64 + 2 * (KS / 2)], const float* __restrict__ src, int x0, int y0, int W, int H, int pitch)
+{
+    constexpr int R = KS / 2, LW = 64 + 2 * R, LH = 16 + 2 * R;
+    const int tid = threadIdx.x;
+    if (x0 + 64 <= W) {
+        constexpr int NV = (LH * 16 + 255) / 256;
+        float4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = tid + 256 * k, ly = i >> 4, q = i & 15;
+            if (i < LH * 16) v[k] = *reinterpret_cast<const float4*>(src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch + x0 + 4 * q);
+        }
+        const bool halo = tid < LH * 2 * R;
+        const int hly = tid / (2 * R), hc = tid % (2 * R), hlx = hc < R ? hc : 64 + hc;
+        float hv = 0.f;
+        if (halo) hv = src[(size_t)clampi(y0 - R + hly, 0, H - 1) * pitch + clampi(x0 - R + hlx, 0, W - 1)];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = tid + 256 * k, ly = i >> 4, q = i & 15;
+            if (i < LH * 16) {
+                float* d = &t[ly][R + 4 * q];
+                if constexpr (R % 2 == 0) {            // 8-byte aligned: two ds_write_b64
+                    *reinterpret_cast<float2*>(d) = make_float2(v[k].x, v[k].y);
+                    *reinterpret_cast<float2*>(d + 2) = make_float2(v[k].z, v[k].w);
+                } else { d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w; }
+            }
+        }
+        if (halo) t[hly][hlx] = hv;
+    } else {
+        constexpr int NS = (LH * LW + 255) / 256;
+        float sv[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = tid + 256 * k, ly = i / LW, lx = i % LW;
+            if (i < LH * LW) sv[k] = src[(size_t)clampi(y0 - R + ly, 0, H - 1) * pitch + clampi(x0 - R + lx, 0, W - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < LH * LW) (&t[0][0])[i] = sv[k];
+        }
+    }
+    __syncthreads();
+}
+
 // median of a staged (TH+2R) x (TW+2R) tile: 5x5 -> each thread produces FOUR horizontally adjacent outputs from one 5x8
 // window (tf_median25_row4: shared column sorts and merges, 76 min/max/med3 per output instead of 198); 3x3 -> one
 // output per thread and row as before.
@@ -475,11 +525,7 @@ __global__ __launch_bounds__(256) void k_median(MedArgs a)
     const float* __restrict__ src = (plane ? a.sb.u2[uc] : a.sb.u1[uc]) + po;
     float* __restrict__ dst = (plane ? a.sb.u2[uc ^ 1] : a.sb.u1[uc ^ 1]) + po;
     const int x0 = blockIdx.x * TWm, y0 = blockIdx.y * THm, W = a.g.w, H = a.g.h, pitch = a.g.pitch;
-    for (int ly = threadIdx.x >> 6; ly < LH; ly += 4) {
-        const float* row = src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch;
-        for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
-    }
-    __syncthreads();
+    median_stage<KS>(t, src, x0, y0, W, H, pitch);
     median_tile<KS, LW>(t, dst, x0, y0, W, H, pitch);
 }
 
@@ -1557,12 +1603,8 @@ template <int KS>
 __device__ __forceinline__ void median_block(float (*t)[64 + 2 * (KS / 2)], const float* __restrict__ src, float* __restrict__ dst,
                                              int x0, int y0, int W, int H, int pitch)
 {
-    constexpr int R = KS / 2, LW = 64 + 2 * R, LH = 16 + 2 * R;
-    for (int ly = threadIdx.x >> 6; ly < LH; ly += 4) {
-        const float* row = src + (size_t)clampi(y0 - R + ly, 0, H - 1) * pitch;
-        for (int lx = threadIdx.x & 63; lx < LW; lx += 64) t[ly][lx] = row[clampi(x0 - R + lx, 0, W - 1)];
-    }
-    __syncthreads();
+    constexpr int R = KS / 2, LW = 64 + 2 * R;
+    median_stage<KS>(t, src, x0, y0, W, H, pitch);
     median_tile<KS, LW>(t, dst, x0, y0, W, H, pitch);
 }
 

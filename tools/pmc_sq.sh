@@ -6,6 +6,7 @@
 set -u
 TAG=${1:-r02}
 ALGO=${2:-TVL1}
+KREGEX=${KREGEX:-"k_iter2_rows|k_df_sor_fused"}     # other kernels: KREGEX="k_median2|k_warp" bash tools/pmc_sq.sh r02x
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_$ALGO
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,7 +16,7 @@ EXTRA=""
 [ "$ALGO" = "deepflow" ] && EXTRA="--batch 64"
 pass() {
   local name=$1; shift
-  timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-include-regex "k_iter2_rows|k_df_sor_fused" --output-format csv -d $OUT/$name -o $name -- \
+  timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-include-regex "$KREGEX" --output-format csv -d $OUT/$name -o $name -- \
     python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --lanes 1 --no-deepflow --algo $ALGO $EXTRA \
     > $OUT/$name.json 2> $OUT/$name.err
   echo "pass $name ($*) rc=$?"

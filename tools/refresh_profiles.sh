@@ -18,9 +18,10 @@ run_stats() {   # name, bench args...
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/${TAG}_bench_$name.json 2> $OUT/$name.err
   echo "stats $name rc=$?"
 }
-# counters first: the pass rewrites profiles/hbm_traffic.json for this build, which the stats runs below then pick up
+# counters first: the pass measures the traffic of THIS build; copied into profiles/ so that the stats runs below carry it
 timeout -k 10 900 python3 $GRAFT_REPO_ROOT/bench.py --pmc --pmc-dir $OUT/pmc_live --round-tag $TAG > $OUT/${TAG}_bench_pmc.json 2> $OUT/bench_pmc.err
 echo "bench --pmc rc=$?"
+[ -f $OUT/pmc_live/hbm_traffic.json ] && cp $OUT/pmc_live/hbm_traffic.json $GRAFT_REPO_ROOT/profiles/hbm_traffic.json
 run_stats default
 run_stats lanes1 --lanes 1 --no-cpu-baseline
 cd $GRAFT_REPO_ROOT
