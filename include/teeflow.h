@@ -210,7 +210,8 @@ int tf_device_count(void);
  * with two iterations per launch), "min_rows_work" (rows*pairs below which tiles are used),
  * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
  * stop reports), "sched" (1 = free-running pair scheduler for batches of >= "sched_min_pairs" pairs, 0 = lock-step
- * stages), "lanes" (independent engine lanes a batch is split over). Results never change. */
+ * stages), "lanes" (independent engine lanes a batch is split over), "warp_margin" (pixels of flow the LDS-staged warp
+ * covers around its tile: 0 = global gathers only, default 8). Results never change. */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);

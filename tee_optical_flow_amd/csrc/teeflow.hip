@@ -125,8 +125,10 @@ struct tf_handle {
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
     int sor_fuse = 4;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); with
                                  // 1024-thread blocks 4 is best (64 pairs @512^2: 460 / 491 / 378 pairs/s for 3 / 4 / 5)
-    int warp_margin = 0;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS.  Measured equal to k_warp on MI355X (both
-                                 // are VALU-bound at ~4 cycles per wave64 instruction), so the simpler gather kernel is the default
+    int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
+                                 // bound by the texture path (~7-10 cycles per scattered dword load and wave); from LDS the same taps cost
+                                 // ~2.  128 pairs @512^2, warp stage per step: 5.0 ms gathers, 3.35 / 3.5 / 3.55 / 3.8 ms for M = 4 / 8 / 12 /
+                                 // 16 (+3.4 % pairs/s).  A pixel displaced by more than M falls back to the gathers, so M only moves time.
     int min_rows_work = 8192;    // rows*pairs of a level below which the tile kernels are used (measured at 512^2 with k_iter2_tile: 16 pairs
                                  // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
@@ -394,7 +396,7 @@ void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s, const f
     }
     const int M = warp_margin_class(h->warp_margin);
     const dim3 grid((g.w + WL_TW - 1) / WL_TW, (g.h + WL_TH - 1) / WL_TH, B);
-    const size_t shm = (size_t)(128 + (WL_TW + 2 * M + 7) * (WL_TH + 2 * M + 7)) * sizeof(float);
+    const size_t shm = (size_t)(128 + (WL_TW + 2 * (M + 4)) * (WL_TH + 2 * M + 7)) * sizeof(float);
     switch (M) {
         case 4: hipLaunchKernelGGL(k_warp_lds<4>, grid, dim3(256), shm, s, wa); break;
         case 8: hipLaunchKernelGGL(k_warp_lds<8>, grid, dim3(256), shm, s, wa); break;

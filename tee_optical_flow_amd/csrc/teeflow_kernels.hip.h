@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_warp_cuda(WarpCudaArgs A)
 // of M pixels (k_warp is L1/TA-bound on its 36 scalar gathers per pixel; ds_read_b32 from a staged tile is ~7x cheaper).
 // A pixel whose 6x6 footprint leaves the staged region (|flow| > ~M) falls back to clamped global loads, so the result
 // never depends on M.  The staged array holds I1 at UNclamped coordinates with replicate content, which is exactly what
-// the clamped patch loads of k_warp read.
+// the clamped patch loads of k_warp read.  All global loads of a thread are in flight together (see median_stage).
 // ---------------------------------------------------------------------------------------------
 #define WL_TW 64
 #define WL_TH 16
@@ -357,29 +357,56 @@ __global__ __launch_bounds__(256) void k_warp_lds(WarpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* stab = smem;                  // [128] bicubic table
-    float* S = smem + 128;               // [SH][SW] staged I1
-    constexpr int SW = WL_TW + 2 * M + 7, SH = WL_TH + 2 * M + 7;      // compile-time: i / SW below is a multiply-shift
+    float* S = smem + 128;               // [SH][SW] staged I1 (16-byte aligned rows)
+    // horizontal margin M + 4 on both sides (the region then starts on a float4 boundary), vertical M + 3 above / M + 4 below
+    constexpr int MX = M + 4, SW = WL_TW + 2 * MX, SH = WL_TH + 2 * M + 7, QW = SW / 4, NQ = QW * SH, NV = (NQ + 255) / 256;
+    static_assert(M % 4 == 0, "margin classes are multiples of 4");
     const int b = blockIdx.z;
     const int W = a.g.w, H = a.g.h, pitch = a.g.pitch;
     const int x0 = blockIdx.x * WL_TW, y0 = blockIdx.y * WL_TH;
-    const int rx0 = x0 - M - 3, ry0 = y0 - M - 3;
+    const int rx0 = x0 - MX, ry0 = y0 - M - 3;
     const float* __restrict__ I0 = a.pyr + (size_t)(a.off0 + b) * a.g.plane;
     const float* __restrict__ I1 = a.pyr + (size_t)(a.off1 + b) * a.g.plane;
-    if (threadIdx.x < 128) stab[threadIdx.x] = a.tab[threadIdx.x];
-    for (int i = threadIdx.x; i < SW * SH; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        S[i] = I1[(size_t)clampi(ry0 + ly, 0, H - 1) * pitch + clampi(rx0 + lx, 0, W - 1)];
-    }
-    __syncthreads();
     const int uc = a.ctl[b].ubase & 1;
     const size_t po = (size_t)b * a.g.splane;
-    const int lx = threadIdx.x & 63, x = x0 + lx;
-    if (x >= W) return;
+    const int lx = threadIdx.x & 63, x = x0 + lx, ty = threadIdx.x >> 6;
+    // everything this thread reads from global memory is requested before the first wait: the flow and I0 of its four
+    // pixels, then its share of the staged region (float4 where the quad lies inside the image, clamped scalars at the border)
+    float u1r[4], u2r[4], i0r[4];
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int y = y0 + (threadIdx.x >> 6) + 4 * r;
+        const int y = y0 + ty + 4 * r;
+        u1r[r] = u2r[r] = i0r[r] = 0.f;
+        if (x < W && y < H) {
+            const size_t idx = (size_t)y * pitch + x;
+            u1r[r] = a.sb.u1[uc][po + idx]; u2r[r] = a.sb.u2[uc][po + idx]; i0r[r] = I0[idx];
+        }
+    }
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NQ) {
+            const int ly = i / QW, gx = rx0 + 4 * (i - ly * QW);
+            const float* row = I1 + (size_t)clampi(ry0 + ly, 0, H - 1) * pitch;
+            if (gx >= 0 && gx + 3 < W) v[k] = *reinterpret_cast<const float4*>(row + gx);
+            else v[k] = make_float4(row[clampi(gx, 0, W - 1)], row[clampi(gx + 1, 0, W - 1)], row[clampi(gx + 2, 0, W - 1)], row[clampi(gx + 3, 0, W - 1)]);
+        }
+    }
+    if (threadIdx.x < 128) stab[threadIdx.x] = a.tab[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NQ) *reinterpret_cast<float4*>(S + 4 * i) = v[k];
+    }
+    __syncthreads();
+    if (x >= W) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + ty + 4 * r;
         if (y >= H) break;
         const size_t idx = (size_t)y * pitch + x;
-        const float u1 = a.sb.u1[uc][po + idx], u2 = a.sb.u2[uc][po + idx];
+        const float u1 = u1r[r], u2 = u2r[r];
         const float mx = (float)x + u1, my = (float)y + u2;
         const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
         const float* wxp = stab + (sx & 31) * 4;
@@ -390,10 +417,11 @@ __global__ __launch_bounds__(256) void k_warp_lds(WarpArgs a)
             float P[6][6];
             const int px = ix - 1 - rx0, py = iy - 1 - ry0;
             if (px >= 0 && py >= 0 && px + 6 <= SW && py + 6 <= SH) {
+                const float* Sp = S + py * SW + px;
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) P[j][i] = S[(py + j) * SW + px + i];
+                    for (int i = 0; i < 6; ++i) P[j][i] = Sp[j * SW + i];
             } else {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(256) void k_warp_lds(WarpArgs a)
         }
         a.wx[po + idx] = vX;
         a.wy[po + idx] = vY;
-        a.rho[po + idx] = ((vI - vX * u1) - vY * u2) - I0[idx];
+        a.rho[po + idx] = ((vI - vX * u1) - vY * u2) - i0r[r];
     }
 }
 
