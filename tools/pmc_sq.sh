@@ -14,6 +14,7 @@ cd /tmp
 [ -f $OUT/../counters_list.txt ] || rocprofv3 -L > $OUT/../counters_list.txt 2>&1
 EXTRA=""
 [ "$ALGO" = "deepflow" ] && EXTRA="--batch 64"
+[ -n "${TUNING:-}" ] && EXTRA="$EXTRA --tuning $TUNING"          # engine knobs for an experiment: TUNING=sor_mw=2 bash tools/pmc_sq.sh x deepflow
 pass() {
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-include-regex "$KREGEX" --output-format csv -d $OUT/$name -o $name -- \
