@@ -123,6 +123,7 @@ struct tf_handle {
     float* wsum = nullptr; size_t wsum_cap = 0;
     float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
+    int df_fuse_ds = 1;          // DeepFlow: data term + smoothness contributions in one kernel (0: k_df_data then k_df_smooth)
     int sor_fuse = 4;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); with
                                  // 1024-thread blocks 4 is best (64 pairs @512^2: 460 / 491 / 378 pairs/s for 3 / 4 / 5)
     int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
@@ -894,8 +895,11 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
     hipLaunchKernelGGL(k_df_grad2, gr, bl, 0, s, d, g);
     const int fuse = h->sor_fuse < 0 ? 0 : (h->sor_fuse > 5 ? 5 : h->sor_fuse);
     for (int fp = 0; fp < h->DP.fixed_point_iterations; ++fp) {
-        hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
-        hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
+        if (h->df_fuse_ds) hipLaunchKernelGGL(k_df_data_smooth, gr, bl, 0, s, d, cur, g, c);
+        else {
+            hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
+            hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
+        }
         int left = h->DP.sor_iterations;
         if (h->sor_whole && fuse > 0 && left > 0 && g.w <= DF_WHOLE && g.h <= DF_WHOLE) {
             ProfEv* pe = nullptr;
@@ -1157,7 +1161,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
-        t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse;
+        t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_mw = h->sor_mw; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
         t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu; t->sched_overlap = h->sched_overlap;
@@ -1425,6 +1429,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
+    else if (n == "df_fuse_ds") h->df_fuse_ds = value ? 1 : 0;
     else if (n == "sched") h->sched = value;
     else if (n == "sched_min_pairs") h->sched_min_pairs = value < 1 ? 1 : value;
     else if (n == "sched_lag") h->sched_lag = value < 1 ? 1 : (value > 64 ? 64 : value);
