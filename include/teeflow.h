@@ -207,7 +207,7 @@ int tf_device_count(void);
 /* ---- kernel-level test hooks (dense host arrays, one image; used by tests/ to compare each kernel
  *      with the oracle bit for bit; not part of the drop-in surface) -------------------------------- */
 /* implementation knobs for experiments: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips, 2 = row strips
- * with two iterations per launch), "min_rows_work" (rows*pairs below which tiles are used),
+ * with two iterations per launch [default], 3 = three per launch where inner_iterations is a multiple of 3), "min_rows_work" (rows*pairs below which tiles are used),
  * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
  * stop reports), "sched" (1 = free-running pair scheduler for batches of >= "sched_min_pairs" pairs, 0 = lock-step
  * stages), "lanes" (independent engine lanes a batch is split over), "warp_margin" (pixels of flow the LDS-staged warp

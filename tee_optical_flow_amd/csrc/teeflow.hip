@@ -11,6 +11,7 @@
 // each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
+#include "teeflow_iter3.hip.h"
 #include "teeflow_sched.hip.h"
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_analysis.hip.h"
@@ -95,6 +96,7 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int iter3_min_w = 0;         // iter_variant 3: levels narrower than this keep the two-iteration kernel
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
                                  // @512^2: 1 lane 2180, 2 lanes 2470, 3 lanes 2415, 4 lanes 2165 pairs/s (DeepFlow 377 vs 309)
@@ -369,6 +371,40 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
 }
 
+// launch one three-iteration tvl1_iter pass (k_iter3_rows); the caller has checked rows_ok()
+void launch_iter3(tf_handle* h, const Iter3Args& A, int B, hipStream_t s, int active_hint = 0)
+{
+    const Geom& g = A.a.g;
+    int R, QX, RY, threads;
+    strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
+    const int LW = QX * 4 + 4;
+    const size_t shmem = (size_t)(48 + 12 * RY * LW + 4 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
+    if (h->dynamic_strips && B <= 1024) {
+        int slots = h->slots_override;
+        if (slots <= 0) {
+            const size_t key = ((size_t)1 << 62) | (shmem * 1024 + (size_t)threads / 64);
+            auto f = h->slots_cache.find(key);
+            if (f == h->slots_cache.end()) {
+                int per_cu = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iter3_rows, threads, shmem);
+                if (per_cu < 1) per_cu = 1;
+                f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
+            }
+            slots = f->second;
+        }
+        int items = 1;
+        for (int n = 1; n <= B; ++n) {
+            int r, sn;
+            strip_rule3(n, g.h, RY, slots, &r, &sn);
+            if (n * sn > items) items = n * sn;
+        }
+        hipLaunchKernelGGL(k_iter3_rows, dim3(items, 1, 1), dim3(threads), shmem, s, A, 0, QX, RY, slots);
+        return;
+    }
+    if (R < 6 * RY) R = 6 * RY;
+    hipLaunchKernelGGL(k_iter3_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
+}
+
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
 void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 {
@@ -451,7 +487,58 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
-    const bool two = cuda_variant || (h->iter_variant == 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
+    const bool three = !cuda_variant && h->iter_variant == 3 && rows_ok(h, g, B) && inner % 3 == 0 && g.w <= 1024 && g.w >= h->iter3_min_w;
+    if (three) {
+        // three iterations per launch; pass index it = 0,3,..,total (the last one can only hold REPLAY blocks)
+        int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
+        bool stop = false;
+        int last_active = B;
+        unsigned checked = h->launch_seq;
+        for (int it = 0; it <= total && !stop; it += 3) {
+            if (it < total && it % inner == 0 && P.median_filtering > 1) {
+                ma.it = it; ma.utog = utog;
+                ProfEv* pm = h->profile ? prof_next(h) : nullptr;
+                if (pm) { pm->level = -5; HIPC(h, hipEventRecord(pm->a, s)); }
+                if (P.median_filtering == 5) hipLaunchKernelGGL(k_median3<5>, gm, dim3(256), 0, s, ma, total);
+                else hipLaunchKernelGGL(k_median3<3>, gm, dim3(256), 0, s, ma, total);
+                if (pm) HIPC(h, hipEventRecord(pm->b, s));
+                ++utog;
+            }
+            const unsigned q = h->launch_seq++;
+            h->slots_host[q % SLOT_RING] = -1;
+            Iter3Args A3;
+            A3.a = ia;
+            A3.a.host_slot = h->slots_dev + q % SLOT_RING;
+            A3.a.it = it; A3.a.utog = utog; A3.a.ptog = ptog; A3.a.pzero = (wi == 0 && it == 0) ? 1 : 0;
+            A3.utog_prev = utog_prev; A3.ptog_prev = ptog_prev; A3.pzero_prev = pzero_prev; A3.total = total;
+            ProfEv* pe = h->profile ? prof_next(h) : nullptr;
+            if (pe) { pe->level = l; pe->warp = wi; pe->it = it; HIPC(h, hipEventRecord(pe->a, s)); }
+            launch_iter3(h, A3, B, s, last_active);
+            if (pe) HIPC(h, hipEventRecord(pe->b, s));
+            ++h->iter_launches;
+            utog_prev = utog; ptog_prev = ptog; pzero_prev = A3.a.pzero;
+            ++utog; ++ptog;
+            while (checked <= q) {
+                int v = h->slots_host[checked % SLOT_RING];
+                if (v < 0) {
+                    if (q - checked < (unsigned)h->lag) break;
+                    const double t0 = now_ms();
+                    while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
+                        if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "tvl1_iter launch %u never reported (GPU hang?)", checked);
+                        if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
+                            return fail(h, TF_ERR_HIP, "stream drained but launch %u did not report", checked);
+                    }
+                }
+                ++checked;
+                if (v == 0) { stop = true; break; }
+                last_active = v;
+            }
+        }
+        hipLaunchKernelGGL(k_stage_end3, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
+                           total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
+        return TF_OK;
+    }
+    const bool two = cuda_variant || (h->iter_variant >= 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
         int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
@@ -1160,7 +1247,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
+        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->iter3_min_w = h->iter3_min_w;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_mw = h->sor_mw; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
@@ -1294,6 +1381,8 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
         return bail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter3_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter2_q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -1416,6 +1505,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lag") h->lag = value < 0 ? DEFAULT_LAG : (value < SLOT_RING / 2 ? value : SLOT_RING / 2);   // 0 = wait for every launch's report (it is published at the launch's start); unread slots must never be overwritten
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
+    else if (n == "iter3_min_w") h->iter3_min_w = value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;

@@ -1448,6 +1448,7 @@ __device__ __forceinline__ void iter2_rows_body(const IterArgs& a, const Iter2Bl
                 st4(o21 + prow, PACK4(r21)); st4(o22 + prow, PACK4(r22));
             }
         }
+        else __syncthreads();       // REPLAY blocks: keep the next step's stage-1 LDS writes behind this step's stage-2 reads
         // ================= rotate the pipeline registers =================
         s2_valid = v2u;
 #pragma unroll

@@ -23,7 +23,7 @@ def main():
         H = int(rng.integers(5, 161)); W = int(rng.integers(5, 201)); B = int(rng.choice([1, 2, 3, 7, 20, 40, 70]))
         p = dict(tau=float(rng.choice([0.25, 0.2, 0.1])), lambda_=float(rng.choice([0.15, 0.05, 0.3, 1.0])),
                  theta=float(rng.choice([0.3, 0.2, 0.5])), nscales=int(rng.integers(1, 7)), warps=int(rng.integers(1, 6)),
-                 epsilon=float(rng.choice([0.01, 0.02, 0.005, 0.05])), inner_iterations=int(rng.choice([30, 10, 7, 2, 1, 16])),
+                 epsilon=float(rng.choice([0.01, 0.02, 0.005, 0.05])), inner_iterations=int(rng.choice([30, 10, 7, 2, 1, 16, 9, 3, 12])),
                  outer_iterations=int(rng.choice([10, 1, 3, 5])), scale_step=float(rng.choice([0.8, 0.5, 0.7, 0.9])),
                  median_filtering=int(rng.choice([5, 3, 1])))
         variant = "cuda" if rng.random() < 0.25 else "cpu"        # TF_VARIANT_CUDA needs an even iteration count
@@ -39,6 +39,9 @@ def main():
         if sched:
             eng.set_tuning("sched", 1); eng.set_tuning("sched_min_pairs", 2); eng.set_tuning("sched_overlap", int(rng.integers(0, 2)))
         eng.set_tuning("lanes", int(rng.choice([1, 2])))
+        k3 = bool(rng.random() < 0.4)                               # three iterations per pass where inner is a multiple of 3
+        if k3:
+            eng.set_tuning("iter_variant", 3)
         flows = eng.calc_pairs(I0s, I1s)
         iters = eng.last_iters()
         op = O.default_params(variant=1 if variant == "cuda" else 0)
@@ -55,7 +58,7 @@ def main():
         bad += not ok
         eng.close()
         print(f"case {c}: {H}x{W} B={B} scales={p['nscales']} warps={p['warps']} inner={p['inner_iterations']} outer={p['outer_iterations']} "
-              f"median={p['median_filtering']} variant={variant} sched={int(sched)} {'ok' if ok else 'FAIL'}", flush=True)
+              f"median={p['median_filtering']} variant={variant} sched={int(sched)} k3={int(k3)} {'ok' if ok else 'FAIL'}", flush=True)
     print(f"{cases - bad}/{cases} cases identical in {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 
