@@ -96,6 +96,7 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int lds_pad_kb = 0;          // experiment: extra dynamic LDS per k_iter2_rows block (lowers the resident blocks per CU)
     int iter3_min_w = 0;         // iter_variant 3: levels narrower than this keep the two-iteration kernel
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
@@ -345,7 +346,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     // short strips (latency of a few steps) instead of a few long ones
     strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
     const int LW = QX * 4 + 4;
-    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 2 * RY * QX) * sizeof(float);
+    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 2 * RY * QX) * sizeof(float) + (size_t)h->lds_pad_kb * 1024;
     if (h->dynamic_strips && B <= 1024) {
         // strips sized on the device from the exact number of pairs still iterating; the grid covers the largest item count
         int slots = h->slots_override;
@@ -1247,7 +1248,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->iter3_min_w = h->iter3_min_w;
+        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->iter3_min_w = h->iter3_min_w; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_mw = h->sor_mw; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
@@ -1506,6 +1507,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
     else if (n == "iter3_min_w") h->iter3_min_w = value;
+    else if (n == "lds_pad_kb") h->lds_pad_kb = value < 0 ? 0 : value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
