@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6
 HBM_STREAM_GBS = 6290.0
 SIMDS = 256 * 4         # 256 CUs x 4 SIMDs
 TVL1_KERNEL = "k_iter2_rows"
-DF_KERNEL = "k_df_sor_fused"
+DF_KERNEL = "k_df_sor_rt"
 # FETCH_SIZE correction (MI355X_MICROARCH.md, HBM): gfx950 tallies the 128-B requests of 16-B-per-lane loads at 64 B, so
-# k_iter2_rows (dwordx4 loads) doubles the counter.  k_df_sor_fused stages its tiles with 8-B-per-lane loads, a width the
+# k_iter2_rows (dwordx4 loads) doubles the counter.  k_df_sor_rt stages its tiles with 8-B-per-lane loads, a width the
 # guide leaves uncalibrated; doubling its count would exceed every byte the kernel requests (8 planes x 4 B x 1.875 halo =
 # 60 B per tile pixel and launch), while the raw count sits between that and the halo-free 32 B -- so it is taken as is.
 FETCH_FACTOR = {"TVL1": 2.0, "deepflow": 1.0}
@@ -575,7 +575,7 @@ def main():
                         "write_size_kb_mean": lp["write_kb"], "launches_profiled": lp.get("launches"), "command": lp.get("command"),
                         "formula": "(fetch_size_factor*FETCH_SIZE + WRITE_SIZE)*1024 per launch, averaged over every launch of the kernel in a 1-step "
                                    "single-lane run; factor 2 for 16-B-per-lane loads per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B), "
-                                   "1 for the 8-B-per-lane staging loads of k_df_sor_fused (see FETCH_FACTOR in bench.py); one --pmc pass per counter",
+                                   "1 for the 8-B-per-lane staging loads of k_df_sor_rt (see FETCH_FACTOR in bench.py); one --pmc pass per counter",
                         "source_fingerprint": out["kernel_source_fingerprint"], "round": a.round_tag}
             if rec:
                 os.makedirs(a.pmc_dir, exist_ok=True)

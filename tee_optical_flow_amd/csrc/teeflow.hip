@@ -14,6 +14,7 @@
 #include "teeflow_iter3.hip.h"
 #include "teeflow_sched.hip.h"
 #include "teeflow_deepflow.hip.h"
+#include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
 #include "teeflow_wase.hip.h"
 #include "../../include/teeflow.h"
@@ -106,13 +107,6 @@ struct tf_handle {
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int slots_override = 0, num_cus = 256;
     int tile_max_w = 0;          // levels this narrow or narrower always take the tile kernels (experiment: see DESIGN section 8)
-    int sor_nt = 1024;           // DeepFlow SOR tile kernel: threads per block (256 | 512 | 1024).  Fewer slots per thread = fewer
-                                 // registers (167 -> 95 -> 60 VGPRs at 3-4 sweeps) = 3 -> 4 -> 8 waves per SIMD: 411 / 470 / 491 pairs/s
-    int sor_whole = 1;           // DeepFlow: levels up to 96 x 96 run a whole fixed-point iteration's SOR in one launch
-    int sor_mw = 1;              // DeepFlow SOR tile form: edge-weight planes in LDS, unconditional neighbour loads (teeflow_deepflow.hip.h)
-    int sor_diet = 0;            // DeepFlow SOR with weights, neighbour addresses and diagonal reciprocals hoisted out of the sweeps: bit-identical,
-                                 // a third fewer instructions per update, but ~110 instead of 60 VGPRs = one 1024-thread block per CU instead
-                                 // of two: 384 instead of 494 pairs/s (64 pairs @512^2).  The kernel lives on its resident waves; kept as a knob
     int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
     int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
                                  // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
@@ -126,9 +120,11 @@ struct tf_handle {
     float* wsum = nullptr; size_t wsum_cap = 0;
     float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
+    int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
+    int sor_rt_shape = 1;        // k_df_sor_rt: 0 = 8 bands x 8 rows (512 threads), 1 = 16 bands x 4 rows (1024 threads)
     int df_fuse_ds = 1;          // DeepFlow: data term + smoothness contributions in one kernel (0: k_df_data then k_df_smooth)
-    int sor_fuse = 4;            // DeepFlow: complete red-black SOR sweeps per launch (0 = one colour per launch, in place); with
-                                 // 1024-thread blocks 4 is best (64 pairs @512^2: 460 / 491 / 378 pairs/s for 3 / 4 / 5)
+    int sor_fuse = 5;            // DeepFlow: complete red-black SOR sweeps per launch of k_df_sor_rt (0 = one colour per launch, in place).
+                                 // 64 pairs @512^2: 466 / 534 / 562 / 548 / 567 pairs/s for 3 / 4 / 5 / 6 / 7; 5 divides the 25 sweeps evenly
     int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
                                  // bound by the texture path (~7-10 cycles per scattered dword load and wave); from LDS the same taps cost
                                  // ~2.  128 pairs @512^2, warp stage per step: 5.0 ms gathers, 3.35 / 3.5 / 3.55 / 3.8 ms for M = 4 / 8 / 12 /
@@ -928,47 +924,26 @@ void df_gauss3(float sigma, float* k0, float* k1)
     *k0 = (float)(t1 * inv); *k1 = (float)(t0 * inv);
 }
 
-template <int S>
-void launch_sor_fused(const DfBufs& d, const Geom& g, int B, float omega, hipStream_t s, int nt = 256, int diet = 0, int mw = 0)
+// register-tile SOR (teeflow_sor_rt.hip.h): `sweeps` sweeps per launch on 128 x (R*NB) regions with a halo of hl = 2 * sweeps
+// (hl = 0: the region holds the whole level)
+template <int R, int NB>
+void launch_sor_rt_t(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, int hl, hipStream_t s)
 {
-    constexpr int RW = 64 + 4 * S, RH = 32 + 4 * S;
-    const dim3 grid((g.w + 63) / 64, (g.h + 31) / 32, B);
-    const size_t shm = (size_t)3 * RW * RH * sizeof(float);
-    if (nt == 1024 && mw && !diet) {
-        const size_t shm4 = (size_t)4 * RW * RH * sizeof(float);             // du, dv, WX, WY x two parities
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<S, 64, 32, 1024, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm4);
-            attr = true;
-        }
-        hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 0, 1>), grid, dim3(1024), shm4, s, d, g, omega, S);
-        return;
-    }
-    if (nt == 1024 && diet) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 1>), grid, dim3(1024), shm, s, d, g, omega, S);
-    else if (nt == 1024) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 1024, 0>), grid, dim3(1024), shm, s, d, g, omega, S);
-    else if (nt == 512) hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 512, 0>), grid, dim3(512), shm, s, d, g, omega, S);
-    else hipLaunchKernelGGL((k_df_sor_fused<S, 64, 32, 256, 0>), grid, dim3(256), shm, s, d, g, omega, S);
+    constexpr int RW = 128, RH = R * NB;
+    const int nx = g.w <= RW ? 1 : 1 + (g.w - RW + (RW - 2 * hl) - 1) / (RW - 2 * hl);
+    const int ny = g.h <= RH ? 1 : 1 + (g.h - RH + (RH - 2 * hl) - 1) / (RH - 2 * hl);
+    hipLaunchKernelGGL((k_df_sor_rt<R, NB>), dim3(nx, ny, B), dim3(64 * NB), 0, s, d, g, omega, sweeps, hl);
 }
-
-// levels that fit one 96 x 96 region: all sweeps of a fixed-point iteration in ONE launch, one block of 1024 threads per pair
-// (a 64 x 64 region for the smallest levels: 2 instead of 5 slots per thread)
-constexpr int DF_WHOLE = 96;
-template <int RGN, int DIET>
-void launch_sor_whole_t(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s)
+// returns the number of sweeps it ran (all of `left` when the level fits one region)
+int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float omega, int left, int fuse, hipStream_t s)
 {
-    constexpr size_t shm = (size_t)(3 * RGN * RGN + RGN / 2 + 4) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_df_sor_fused<0, RGN, RGN, 1024, DIET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_df_sor_fused<0, RGN, RGN, 1024, DIET>), dim3(1, 1, B), dim3(1024), shm, s, d, g, omega, sweeps);
-}
-void launch_sor_whole(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, hipStream_t s, int diet)
-{
-    // the 96 x 96 region gives a thread 5 slots: the hoisted per-slot values do not fit its registers, it keeps the plain form
-    if (g.w <= 64 && g.h <= 64) { if (diet) launch_sor_whole_t<64, 1>(d, g, B, omega, sweeps, s); else launch_sor_whole_t<64, 0>(d, g, B, omega, sweeps, s); }
-    else launch_sor_whole_t<DF_WHOLE, 0>(d, g, B, omega, sweeps, s);
+    const int RH = 64;
+    const bool whole = g.w <= 128 && g.h <= RH;
+    const int n = whole ? left : (left < fuse ? left : fuse);
+    const int hl = whole ? 0 : 2 * n;
+    if (h->sor_rt_shape == 0) launch_sor_rt_t<8, 8>(d, g, B, omega, n, hl, s);
+    else launch_sor_rt_t<4, 16>(d, g, B, omega, n, hl, s);
+    return n;
 }
 
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
@@ -981,7 +956,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
     hipLaunchKernelGGL(k_df_warp, gr, bl, 0, s, pyr_l, off0, off1, d, cur, g);
     hipLaunchKernelGGL(k_df_grad1, gr, bl, 0, s, d, g);
     hipLaunchKernelGGL(k_df_grad2, gr, bl, 0, s, d, g);
-    const int fuse = h->sor_fuse < 0 ? 0 : (h->sor_fuse > 5 ? 5 : h->sor_fuse);
+    const int fuse = h->sor_fuse < 0 ? 0 : h->sor_fuse;
     for (int fp = 0; fp < h->DP.fixed_point_iterations; ++fp) {
         if (h->df_fuse_ds) hipLaunchKernelGGL(k_df_data_smooth, gr, bl, 0, s, d, cur, g, c);
         else {
@@ -989,7 +964,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
         }
         int left = h->DP.sor_iterations;
-        if (h->sor_whole && fuse > 0 && left > 0 && g.w <= DF_WHOLE && g.h <= DF_WHOLE) {
+        while (h->sor_rt && fuse > 0 && left > 0) {
             ProfEv* pe = nullptr;
             if (h->profile) {
                 if (h->prof_used == h->prof_pool.size()) {
@@ -999,40 +974,17 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
                 if (h->prof_used < h->prof_pool.size()) { pe = &h->prof_pool[h->prof_used++]; (void)hipEventRecord(pe->a, s); }
             }
             ++h->iter_launches;
-            h->df_sor_bytes += (double)left * g.w * g.h * B * 40.0;
-            launch_sor_whole(d, g, B, c.omega, left, s, h->sor_diet);
-            if (pe) (void)hipEventRecord(pe->b, s);
-            std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
-            left = 0;
-        }
-        while (left > 0) {
-            const int n = fuse > 0 ? (left < fuse ? left : fuse) : 0;
-            if (n == 0) {     // one colour per launch, in place
-                hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 0, c.omega);
-                hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 1, c.omega);
-                --left;
-                continue;
-            }
-            ProfEv* pe = nullptr;
-            if (h->profile) {
-                if (h->prof_used == h->prof_pool.size()) {
-                    ProfEv ne;
-                    if (hipEventCreate(&ne.a) == hipSuccess && hipEventCreate(&ne.b) == hipSuccess) h->prof_pool.push_back(ne);
-                }
-                if (h->prof_used < h->prof_pool.size()) { pe = &h->prof_pool[h->prof_used++]; (void)hipEventRecord(pe->a, s); }
-            }
-            ++h->iter_launches;
-            h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;   // one sweep: 8 planes read + du, dv written
-            switch (n) {   // n complete sweeps in one launch: (du,dv) -> (du2,dv2), then the roles swap
-                case 1: launch_sor_fused<1>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
-                case 2: launch_sor_fused<2>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
-                case 3: launch_sor_fused<3>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
-                case 4: launch_sor_fused<4>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
-                default: launch_sor_fused<5>(d, g, B, c.omega, s, h->sor_nt, h->sor_diet, h->sor_mw); break;
-            }
+            const int n = launch_sor_rt(h, d, g, B, c.omega, left, fuse > 8 ? 8 : fuse, s);
+            h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;
             if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
             left -= n;
+        }
+        while (left > 0) {     // sor_fuse = 0 (or sor_rt = 0): one colour per launch, in place -- the plain form the others are tested against
+            hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 0, c.omega);
+            hipLaunchKernelGGL(k_df_sor, gsor, bl, 0, s, d, g, 1, c.omega);
+            h->df_sor_bytes += (double)g.w * g.h * B * 40.0;
+            --left;
         }
     }
     hipLaunchKernelGGL(k_df_sum, gr, bl, 0, s, d, cur, g);
@@ -1251,7 +1203,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->iter3_min_w = h->iter3_min_w; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_whole = h->sor_whole; t->sor_diet = h->sor_diet; t->sor_mw = h->sor_mw; t->sor_nt = h->sor_nt; t->tile_max_w = h->tile_max_w;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->tile_max_w = h->tile_max_w;
         t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu; t->sched_overlap = h->sched_overlap;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
@@ -1512,10 +1464,8 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
     else if (n == "tile_max_w") h->tile_max_w = value;
-    else if (n == "sor_whole") h->sor_whole = value;
-    else if (n == "sor_diet") h->sor_diet = value;
-    else if (n == "sor_mw") h->sor_mw = value;
-    else if (n == "sor_nt") h->sor_nt = value == 1024 ? 1024 : (value == 512 ? 512 : 256);
+    else if (n == "sor_rt") h->sor_rt = value ? 1 : 0;
+    else if (n == "sor_rt_shape") h->sor_rt_shape = value;
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;

@@ -28,7 +28,7 @@ def test_fingerprint_gates_stored_records(tmp_path, monkeypatch):
     (prof / "hbm_traffic.json").write_text(json.dumps({"k_iter2_rows": {"bytes_per_launch": 5.0, "source_fingerprint": fp, "round": "r02"}}))
     rec, why = bench.stored_record("hbm_traffic.json", "k_iter2_rows")
     assert why is None and rec["bytes_per_launch"] == 5.0
-    rec, why = bench.stored_record("hbm_traffic.json", "k_df_sor_fused")
+    rec, why = bench.stored_record("hbm_traffic.json", "k_df_sor_rt")
     assert rec is None and "no record" in why
 
 

@@ -33,11 +33,12 @@ def test_blur_bit_exact(deep, oracle, shape):
     assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("fuse,nt,whole", [(0, 256, 0), (1, 256, 0), (2, 512, 0), (3, 256, 0), (4, 1024, 1), (4, 1024, 0), (5, 512, 1), (5, 1024, 0)])
-@pytest.mark.parametrize("shape,amp", [((64, 64), 1.0), ((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((70, 200), 2.0), ((96, 96), 3.0)])
-def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, nt, whole):
+@pytest.mark.parametrize("fuse,shape_knob", [(0, 0), (1, 0), (2, 1), (3, 0), (3, 1), (4, 1), (5, 0), (5, 1), (6, 1), (7, 0), (8, 1)])
+@pytest.mark.parametrize("shape,amp", [((64, 64), 1.0), ((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((70, 200), 2.0), ((96, 96), 3.0), ((150, 301), 2.0), ((333, 141), 1.0)])
+def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_knob):
     """One cv::VariationalRefinement::calcUV (warp, 8 derivative planes, 5 x [data term, smoothness, 25 red-black SOR sweeps]) in
-    every SOR form: one colour per launch, n sweeps per launch on tiles with 256 / 512 / 1024 threads, whole level in one launch."""
+    every SOR form: one colour per launch (fuse 0), n sweeps per launch of the register-tile kernel on 128 x 64 regions held by
+    8 bands x 8 rows (shape 0) or 16 bands x 4 rows (shape 1); a level that fits one region runs all 25 sweeps in one launch."""
     from scipy import ndimage
     from tee_optical_flow_amd import _lib
     L = _lib.load()
@@ -49,18 +50,18 @@ def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, nt, wh
     v = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
     ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
     gu, gv = u.copy(), v.copy()
-    deep.set_tuning("sor_fuse", fuse)      # 0: one colour per launch; n: n complete sweeps per launch on LDS tiles with a 2n halo
-    deep.set_tuning("sor_nt", nt)
-    deep.set_tuning("sor_whole", whole)    # levels up to 96 x 96: all 25 sweeps in one launch
-    _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    deep.set_tuning("sor_fuse", fuse)
+    deep.set_tuning("sor_rt_shape", shape_knob)
+    try:
+        _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    finally:
+        deep.set_tuning("sor_fuse", 5)
+        deep.set_tuning("sor_rt_shape", 1)
     assert np.array_equal(gu, ru), f"u: {np.sum(gu != ru)} differ, max {np.abs(gu - ru).max()}"
     assert np.array_equal(gv, rv)
-    deep.set_tuning("sor_fuse", 4)
-    deep.set_tuning("sor_nt", 1024)
-    deep.set_tuning("sor_whole", 1)
 
 
-@pytest.mark.parametrize("seed,H,W", [(0, 96, 96), (1, 120, 160), (2, 64, 200)])
+@pytest.mark.parametrize("seed,H,W", [(0, 96, 96), (1, 120, 160), (2, 64, 200), (3, 100, 75), (4, 55, 123), (5, 75, 139)])     # odd widths: the last lane's second column is row padding
 def test_deepflow_pair_matches_oracle(deep, oracle, seed, H, W):
     from tee_optical_flow_amd.synth import speckle_pair
     I0, I1, truth = speckle_pair(seed, H, W)

@@ -3,7 +3,7 @@
   <tag>_bench_{default,lanes1}_kernel_stats.csv + .json   rocprofv3 --kernel-trace --stats summaries and the lines those runs printed
   <tag>_bench_pmc.json                                      the line of `bench.py --pmc` (roofline.traffic measured in that run)
   hbm_traffic.json                                          FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels, tagged with the kernel source fingerprint
-  <tag>_sq_counters.json                                    SQ / GRBM counters of k_iter2_rows and k_df_sor_fused: totals, per-launch means, derived shares
+  <tag>_sq_counters.json                                    SQ / GRBM counters of k_iter2_rows and k_df_sor_rt: totals, per-launch means, derived shares
 usage: python tools/collect_profiles.py r02 [destination directory, default profiles/]"""
 import collections
 import csv
@@ -99,7 +99,7 @@ def main():
     if os.path.exists(ht):
         shutil.copy(ht, os.path.join(DST, "hbm_traffic.json"))
     sq = {}
-    for algo, kern in (("TVL1", "k_iter2_rows"), ("deepflow", "k_df_sor_fused")):
+    for algo, kern in (("TVL1", "k_iter2_rows"), ("deepflow", "k_df_sor_rt")):
         s = sq_summary(tag, algo, kern)
         if s:
             sq[kern] = s

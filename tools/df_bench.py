@@ -19,7 +19,7 @@ def main():
     fr = torch.from_numpy(np.concatenate([I0s, I1s])).cuda()
     fl = torch.empty((B, 512, 512, 2), dtype=torch.float32, device="cuda")
     e = T.DenseFlow(algo="deepflow", max_batch=B)
-    for kv in filter(None, os.environ.get("DF_TUNING", "").split(",")):     # e.g. DF_TUNING=sor_whole=0
+    for kv in filter(None, os.environ.get("DF_TUNING", "").split(",")):     # e.g. DF_TUNING=sor_rt_shape=0
         k, v = kv.split("=")
         e.set_tuning(k, int(v))
     p0 = fr.data_ptr()

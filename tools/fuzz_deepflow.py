@@ -25,8 +25,10 @@ def main():
         if rng.random() < 0.25:
             I1s[0] = I0s[0]
         eng = T.DenseFlow(algo="deepflow", max_batch=int(rng.choice([B, max(1, B // 2)])))
-        eng.set_tuning("sor_fuse", int(rng.choice([0, 1, 2, 3, 4, 5])))
-        eng.set_tuning("sor_nt", int(rng.choice([256, 512, 1024])))
+        shape = int(rng.choice([0, 1]))                   # register-tile SOR: 8 bands x 8 rows / 16 bands x 4 rows
+        fuse = int(rng.choice([0, 1, 2, 3, 4, 5, 5, 6, 7, 8]))   # sweeps per launch (0: one colour per launch)
+        eng.set_tuning("sor_rt_shape", shape)
+        eng.set_tuning("sor_fuse", fuse)
         flows = eng.calc_pairs(I0s, I1s)
         ok = True
         for b in sorted(set([0, B - 1])):
@@ -36,7 +38,7 @@ def main():
                 print(f"MISMATCH case {c} pair {b}: {H}x{W} B={B}: {np.sum(flows[b] != ref)} values differ, max {np.abs(flows[b] - ref).max()}", flush=True)
         bad += not ok
         eng.close()
-        print(f"case {c}: {H}x{W} B={B} {'ok' if ok else 'FAIL'}", flush=True)
+        print(f"case {c}: {H}x{W} B={B} shape={shape} fuse={fuse} {'ok' if ok else 'FAIL'}", flush=True)
     print(f"{cases - bad}/{cases} cases identical in {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 

@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r02}
 ALGO=${2:-TVL1}
-KREGEX=${KREGEX:-"k_iter2_rows|k_df_sor_fused"}     # other kernels: KREGEX="k_median2|k_warp" bash tools/pmc_sq.sh r02x
+KREGEX=${KREGEX:-"k_iter2_rows|k_df_sor_rt"}     # other kernels: KREGEX="k_median2|k_warp" bash tools/pmc_sq.sh r02x
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_$ALGO
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -14,7 +14,7 @@ cd /tmp
 [ -f $OUT/../counters_list.txt ] || rocprofv3 -L > $OUT/../counters_list.txt 2>&1
 EXTRA=""
 [ "$ALGO" = "deepflow" ] && EXTRA="--batch 64"
-[ -n "${TUNING:-}" ] && EXTRA="$EXTRA --tuning $TUNING"          # engine knobs for an experiment: TUNING=sor_mw=2 bash tools/pmc_sq.sh x deepflow
+[ -n "${TUNING:-}" ] && EXTRA="$EXTRA --tuning $TUNING"          # engine knobs for an experiment: TUNING=sor_fuse=7 bash tools/pmc_sq.sh x deepflow
 pass() {
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-include-regex "$KREGEX" --output-format csv -d $OUT/$name -o $name -- \
