@@ -14,7 +14,7 @@ same JSON line.
 Everything that is not GPU work (synthetic inputs, the optional `--pmc` counter passes, which run this script as a
 child under rocprofv3) happens BEFORE the first GPU call, so no process is ever started from a GPU-initialised one.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 from a plain shell: this process starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -42,6 +42,46 @@ DF_KERNEL = "k_df_sor_rt"
 # guide leaves uncalibrated; doubling its count would exceed every byte the kernel requests (8 planes x 4 B x 1.875 halo =
 # 60 B per tile pixel and launch), while the raw count sits between that and the halo-free 32 B -- so it is taken as is.
 FETCH_FACTOR = {"TVL1": 2.0, "deepflow": 1.0}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the CPU-only parent starts one child per GPU (it never imports torch or touches HIP)
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv, script=None, timeout=None):
+    """Run `script argv` as n rank processes of one node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the
+    way torch.distributed.run sets them), relay rank 0's stdout, and return (rc, rank-0 stdout).  rc is the first
+    non-zero child code (a killed child counts).  No exec: the children are ordinary subprocesses of a parent that has
+    not initialised the GPU."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool: RCCL needs it in every rank
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc, out0 = 0, ""
+    t_end = None if timeout is None else time.time() + timeout
+    try:
+        out0 = procs[0].communicate(timeout=timeout)[0].decode(errors="replace")
+        for p_ in procs:
+            left = None if t_end is None else max(1.0, t_end - time.time())
+            p_.wait(timeout=left)
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p_ in procs:                      # exactly the processes started here, never a pattern
+            if p_.poll() is None:
+                p_.kill()
+                p_.wait()
+    for p_ in procs:
+        if p_.returncode and not rc:
+            rc = p_.returncode if p_.returncode > 0 else 128 - p_.returncode
+    return rc, out0
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -521,10 +561,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: be the launcher.  Nothing in this process has touched the GPU (torch is not even
+        # imported yet); the ranks are children, their rank 0 prints the line, we pass it on.
+        rc, line = spawn_ranks(a.gpus, sys.argv[1:])
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        raise SystemExit(rc)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     # ---- CPU-only preparation: nothing below this block may start a process ------------------------------------

@@ -63,7 +63,14 @@ def load():
         raise OpticalFlowCalculationError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C tee_optical_flow_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    # The CPU checker (oracle/libteeflow_cpu.so, test infrastructure) exports the same ABI.  It must never stand in for the
+    # product: refuse anything that lives under an oracle/ directory or carries the checker's own entry points.
+    real = os.path.realpath(LIB_PATH)
+    if "oracle" in real.split(os.sep)[:-1]:
+        raise OpticalFlowCalculationError(f"{LIB_PATH} resolves into an oracle/ directory: the CPU checker is test infrastructure, not a backend")
     L = C.CDLL(LIB_PATH)
+    if hasattr(L, "orc_set_num_threads") or hasattr(L, "orc_tvl1_calc"):
+        raise OpticalFlowCalculationError(f"{LIB_PATH} is the CPU checker library (it exports orc_* symbols): there is no CPU backend")
     vp, i32, f32, dbl = C.c_void_p, C.c_int, C.c_float, C.c_double
     L.tf_abi_version.restype = i32
     L.tf_device_count.restype = i32

@@ -12,6 +12,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The parity tests must exercise the in-tree HIP library: an environment that redirects the binding is refused."""
+    if os.environ.get("TEEFLOW_LIB") and any(it.get_closest_marker("gpu") for it in items):
+        raise pytest.UsageError("TEEFLOW_LIB is set: -m gpu tests run only against tee_optical_flow_amd/libteeflow_hip.so "
+                                "(the override exists for A/B builds of the product in tools/, never for tests)")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure). Built on demand with gcc."""

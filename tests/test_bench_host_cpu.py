@@ -59,3 +59,25 @@ def test_fetch_factors_and_committed_records_are_well_formed():
             d = json.load(open(p))
             for kern, rec in d.items():
                 assert "source_fingerprint" in rec and len(rec["source_fingerprint"]) == 16, (name, kern)
+
+
+def test_spawn_ranks_sets_the_rendezvous_and_reports_failures(tmp_path):
+    """`python bench.py --gpus N` from a plain shell starts its own ranks.  The launcher itself, on a child
+    that needs no GPU: every rank sees RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; rank 0's stdout comes back; a failing rank
+    makes the whole run fail."""
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text("import json, os, sys\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "open(sys.argv[1] + f'/rank{r}.json', 'w').write(json.dumps({k: os.environ.get(k) for k in "
+                     "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')}))\n"
+                     "print(json.dumps({'n_gpus': int(os.environ['WORLD_SIZE']), 'rank': r}))\n"
+                     "sys.exit(int(sys.argv[2]) if r == 1 else 0)\n")
+    rc, out = bench.spawn_ranks(3, [str(tmp_path), "0"], script=str(child), timeout=60)
+    assert rc == 0 and json.loads(out) == {"n_gpus": 3, "rank": 0}
+    envs = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert {e["WORLD_SIZE"] for e in envs} == {"3"} and {e["MASTER_ADDR"] for e in envs} == {"127.0.0.1"}
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and {e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in envs} == {"0"}
+    rc, out = bench.spawn_ranks(2, [str(tmp_path), "7"], script=str(child), timeout=60)
+    assert rc == 7 and json.loads(out)["rank"] == 0

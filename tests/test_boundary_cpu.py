@@ -136,3 +136,27 @@ def test_comm_entry_points_fail_cleanly_without_a_handle():
     assert L.tf_allgather_flows(None, None, 0, None, None) == 1
     assert L.tf_comm_init_all(None, 0) == 1 and L.tf_comm_unique_id(None) == 1
     assert _lib.COMM_ID_BYTES == 128
+
+
+def test_binding_refuses_the_cpu_checker(oracle, monkeypatch, tmp_path):
+    """the checker exports the product's ABI, so the binding itself must refuse it -- by location (anything
+    under an oracle/ directory) and by content (a copy elsewhere still carries orc_* symbols)."""
+    import shutil
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd import _lib
+    from tests import abi_driver as D
+    assert os.path.exists(D.CPU_LIB)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", D.CPU_LIB)
+    with pytest.raises(T.OpticalFlowCalculationError, match="oracle/ directory"):
+        _lib.load()
+    moved = tmp_path / "libteeflow_hip.so"
+    shutil.copy(D.CPU_LIB, moved)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(moved))
+    with pytest.raises(T.OpticalFlowCalculationError, match="CPU checker"):
+        _lib.load()
+    link = tmp_path / "link.so"
+    os.symlink(D.CPU_LIB, link)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(link))
+    with pytest.raises(T.OpticalFlowCalculationError, match="oracle/ directory"):
+        _lib.load()
