@@ -438,15 +438,9 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             full = None
             if prof is not None and len(prof[3]):
                 lv, wp, it, ms = prof
-                if (lv == -1).any():                             # scheduler driver: the launch's own pixel-iteration count is recorded
-                    work = wp.astype(np.float64) * 1024.0
-                    m = (lv == -1) & (ms > 0) & (work >= 0.8 * work.max())
-                    if m.any():
-                        full = float(np.median(work[m] / (ms[m] * 1e-3)))
-                else:
-                    m = (lv == 0) & (it == 0) & (ms > 0)         # first launch of a level-0 stage: all B pairs iterate, 2 iterations
-                    if m.any():
-                        full = float(np.median(B * H * W * 2.0 / (ms[m] * 1e-3)))
+                m = (lv == 0) & (it == 0) & (ms > 0)             # first launch of a level-0 stage: all B pairs iterate, 2 iterations
+                if m.any():
+                    full = float(np.median(B * H * W * 2.0 / (ms[m] * 1e-3)))
             isa, why = stored_record("isa_stats.json", kern)
             valu = {"px_iterations_per_s_all_launches": rate, "px_iterations_per_s_full_launches": full}
             if isa:
@@ -478,8 +472,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         if not a.no_profile and algo == "TVL1":
             # where a step's device time goes, from the library's own event pairs (instrumented single-lane repeats)
             out["stage_ms_per_step"] = {"tvl1_iter": acc["iter_ms"] / steps, "warp": acc.get("p_ms_warp", 0.0) / steps,
-                                        "median": acc.get("p_ms_median", 0.0) / steps, "misc_tiles(warp+median+upsample+output)": acc.get("p_ms_misc", 0.0) / steps,
-                                        "scheduler": acc.get("p_ms_sched", 0.0) / steps, "device_total": acc.get("p_ms_device", 0.0) / steps}
+                                        "median": acc.get("p_ms_median", 0.0) / steps, "device_total": acc.get("p_ms_device", 0.0) / steps}
         if algo == "TVL1":
             out["executed_inner_iterations_per_pair"] = acc["inner"] / (B * steps)
             out["executed_outer_iterations_per_pair"] = acc["outer"] / (B * steps)

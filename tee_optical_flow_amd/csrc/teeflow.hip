@@ -11,8 +11,6 @@
 // each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
-#include "teeflow_iter3.hip.h"
-#include "teeflow_sched.hip.h"
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
@@ -98,7 +96,6 @@ struct tf_handle {
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
     int lds_pad_kb = 0;          // experiment: extra dynamic LDS per k_iter2_rows block (lowers the resident blocks per CU)
-    int iter3_min_w = 0;         // iter_variant 3: levels narrower than this keep the two-iteration kernel
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
                                  // @512^2: 1 lane 2180, 2 lanes 2470, 3 lanes 2415, 4 lanes 2165 pairs/s (DeepFlow 377 vs 309)
@@ -133,18 +130,10 @@ struct tf_handle {
                                  // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
-    // free-running pair scheduler (teeflow_sched.hip.h): every pair walks through its own stages; used when the batch is
-    // large enough for the row strips, the level count fits SC_MAXLEV and the frames are at most 1024 px wide
-    int sched = 0, sched_min_pairs = 24, sched_lag = 2, misc_blocks_per_cu = 8;
-    int sched_overlap = 1;       // k_misc_q of a super-step runs on a second stream beside k_iter2_q (they touch different pairs)
-    hipStream_t misc_stream = nullptr; hipEvent_t sc_ev[16] = {};
-    PairSt* sc_st = nullptr; int* sc_cnt = nullptr; int* sc_items = nullptr; int sc_items_cap = 0;
-    int* sc_mpair = nullptr; int* sc_mpref = nullptr; double* sc_work = nullptr; int sc_work_cap = 0;
-    std::vector<double> sc_work_host;
     // RCCL: one communicator rank per handle, its own stream, a small ring of completion events
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 0;
     hipStream_t comm_stream = nullptr; hipEvent_t comm_ev[8] = {}; hipEvent_t comm_ready = nullptr; unsigned comm_tickets = 0;
-    double misc_ms = 0, sched_ms = 0, warp_ms = 0, median_ms = 0;   // profiling: summed launch durations per stage of the last call
+    double warp_ms = 0, median_ms = 0;   // profiling: summed launch durations per stage of the last call
 };
 
 TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out);
@@ -213,8 +202,6 @@ void free_buffers(tf_handle* h)
     F(h->cwx); F(h->cwy); F(h->crho);
     for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
     F(h->ctl); F(h->errs); F(h->iters_dev);
-    F(h->sc_st); F(h->sc_cnt); F(h->sc_items); F(h->sc_mpair); F(h->sc_mpref); F(h->sc_work);
-    h->sc_items_cap = h->sc_work_cap = 0;
     F(h->st_u8); F(h->st_flow);
     F(h->dpyr_base); F(h->dtmp); F(h->dplanes);
     F(h->an_rad); F(h->an_lon); h->anN = 0;
@@ -269,15 +256,6 @@ int ensure_alloc(tf_handle* h, int H, int W, int B)
     HIPC(h, hipMalloc(&h->errs, cap * (size_t)h->errstride * sizeof(u64)));
     h->iters_cap = cap * (size_t)h->nlev * (size_t)h->P.warps * 2;
     HIPC(h, hipMalloc(&h->iters_dev, h->iters_cap * sizeof(int)));
-    // scheduler state and work lists
-    HIPC(h, hipMalloc(&h->sc_st, cap * sizeof(PairSt)));
-    HIPC(h, hipMalloc(&h->sc_cnt, SC_CNT_WORDS * sizeof(int)));
-    h->sc_items_cap = 8192 + 2 * (int)cap;
-    HIPC(h, hipMalloc(&h->sc_items, (size_t)h->sc_items_cap * sizeof(int)));
-    HIPC(h, hipMalloc(&h->sc_mpair, cap * sizeof(int)));
-    HIPC(h, hipMalloc(&h->sc_mpref, (cap + 1) * sizeof(int)));
-    h->sc_work_cap = h->nlev * h->P.warps * (3 + h->P.outer_iterations + total / 2) + h->nlev + 16;
-    HIPC(h, hipMalloc(&h->sc_work, (size_t)h->sc_work_cap * sizeof(double)));
     h->H = H; h->W = W; h->cap = want_cap;
     h->alloc_scale_step = h->P.scale_step; h->alloc_nscales = h->P.nscales;
     return TF_OK;
@@ -368,40 +346,6 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
 }
 
-// launch one three-iteration tvl1_iter pass (k_iter3_rows); the caller has checked rows_ok()
-void launch_iter3(tf_handle* h, const Iter3Args& A, int B, hipStream_t s, int active_hint = 0)
-{
-    const Geom& g = A.a.g;
-    int R, QX, RY, threads;
-    strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
-    const int LW = QX * 4 + 4;
-    const size_t shmem = (size_t)(48 + 12 * RY * LW + 4 * (RY + 1) * LW + 4 * RY * QX) * sizeof(float);
-    if (h->dynamic_strips && B <= 1024) {
-        int slots = h->slots_override;
-        if (slots <= 0) {
-            const size_t key = ((size_t)1 << 62) | (shmem * 1024 + (size_t)threads / 64);
-            auto f = h->slots_cache.find(key);
-            if (f == h->slots_cache.end()) {
-                int per_cu = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iter3_rows, threads, shmem);
-                if (per_cu < 1) per_cu = 1;
-                f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
-            }
-            slots = f->second;
-        }
-        int items = 1;
-        for (int n = 1; n <= B; ++n) {
-            int r, sn;
-            strip_rule3(n, g.h, RY, slots, &r, &sn);
-            if (n * sn > items) items = n * sn;
-        }
-        hipLaunchKernelGGL(k_iter3_rows, dim3(items, 1, 1), dim3(threads), shmem, s, A, 0, QX, RY, slots);
-        return;
-    }
-    if (R < 6 * RY) R = 6 * RY;
-    hipLaunchKernelGGL(k_iter3_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
-}
-
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
 void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 {
@@ -484,57 +428,6 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
-    const bool three = !cuda_variant && h->iter_variant == 3 && rows_ok(h, g, B) && inner % 3 == 0 && g.w <= 1024 && g.w >= h->iter3_min_w;
-    if (three) {
-        // three iterations per launch; pass index it = 0,3,..,total (the last one can only hold REPLAY blocks)
-        int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
-        bool stop = false;
-        int last_active = B;
-        unsigned checked = h->launch_seq;
-        for (int it = 0; it <= total && !stop; it += 3) {
-            if (it < total && it % inner == 0 && P.median_filtering > 1) {
-                ma.it = it; ma.utog = utog;
-                ProfEv* pm = h->profile ? prof_next(h) : nullptr;
-                if (pm) { pm->level = -5; HIPC(h, hipEventRecord(pm->a, s)); }
-                if (P.median_filtering == 5) hipLaunchKernelGGL(k_median3<5>, gm, dim3(256), 0, s, ma, total);
-                else hipLaunchKernelGGL(k_median3<3>, gm, dim3(256), 0, s, ma, total);
-                if (pm) HIPC(h, hipEventRecord(pm->b, s));
-                ++utog;
-            }
-            const unsigned q = h->launch_seq++;
-            h->slots_host[q % SLOT_RING] = -1;
-            Iter3Args A3;
-            A3.a = ia;
-            A3.a.host_slot = h->slots_dev + q % SLOT_RING;
-            A3.a.it = it; A3.a.utog = utog; A3.a.ptog = ptog; A3.a.pzero = (wi == 0 && it == 0) ? 1 : 0;
-            A3.utog_prev = utog_prev; A3.ptog_prev = ptog_prev; A3.pzero_prev = pzero_prev; A3.total = total;
-            ProfEv* pe = h->profile ? prof_next(h) : nullptr;
-            if (pe) { pe->level = l; pe->warp = wi; pe->it = it; HIPC(h, hipEventRecord(pe->a, s)); }
-            launch_iter3(h, A3, B, s, last_active);
-            if (pe) HIPC(h, hipEventRecord(pe->b, s));
-            ++h->iter_launches;
-            utog_prev = utog; ptog_prev = ptog; pzero_prev = A3.a.pzero;
-            ++utog; ++ptog;
-            while (checked <= q) {
-                int v = h->slots_host[checked % SLOT_RING];
-                if (v < 0) {
-                    if (q - checked < (unsigned)h->lag) break;
-                    const double t0 = now_ms();
-                    while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
-                        if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "tvl1_iter launch %u never reported (GPU hang?)", checked);
-                        if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
-                            return fail(h, TF_ERR_HIP, "stream drained but launch %u did not report", checked);
-                    }
-                }
-                ++checked;
-                if (v == 0) { stop = true; break; }
-                last_active = v;
-            }
-        }
-        hipLaunchKernelGGL(k_stage_end3, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
-                           total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
-        return TF_OK;
-    }
     const bool two = cuda_variant || (h->iter_variant >= 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
@@ -681,152 +574,6 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
         hipLaunchKernelGGL(k_ctl_set, dim3((B + 255) / 256), dim3(256), 0, s, h->ctl, B, 1);
     }
     hipLaunchKernelGGL(k_output, grid64x4(g0, B), dim3(256), 0, s, h->sb, h->ctl, g0, scale, dflow);
-    HIPC(h, hipGetLastError());
-    return TF_OK;
-}
-
-// ---- free-running pair scheduler (teeflow_sched.hip.h) ---------------------------------------------------------------
-bool sched_ok(const tf_handle* h, int B)
-{
-    const tf_params& P = h->P;
-    return h->sched && P.variant == TF_VARIANT_CPU && h->iter_variant == 2 && P.inner_iterations % 2 == 0 && h->nlev <= SC_MAXLEV && h->lv[0].w <= 1024 &&
-           B >= h->sched_min_pairs && B <= 1024 && rows_ok(h, h->lv[0], B);
-}
-
-// Same contract as solve_resident.  The host only enqueues super-steps (k_sched, k_misc_q, k_iter2_q) until the device
-// reports that every pair is done; it reads those reports `sched_lag` super-steps late and never blocks the stream.
-int solve_resident_sched(tf_handle* h, const uint8_t* dframes, int F, int B, int off0, int off1, float scale, float* dflow)
-{
-    const tf_params& P = h->P;
-    hipStream_t s = h->stream;
-    const Geom g0 = h->lv[0];
-    const int total = P.inner_iterations * P.outer_iterations;
-    if (h->src_f32) hipLaunchKernelGGL(k_f32_to_level0, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, (const float*)dframes, h->pyr[0], g0);
-    else hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
-    for (int l = 1; l < h->nlev; ++l) {
-        const double sc = 1.0 / P.scale_step;
-        hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc);
-    }
-    const int Lc = h->nlev - 1;
-    HIPC(h, hipMemset2DAsync(h->sb.u1[0], (size_t)h->lv[Lc].splane * sizeof(float), 0, (size_t)h->lv[Lc].plane * sizeof(float), B, s));
-    HIPC(h, hipMemset2DAsync(h->sb.u2[0], (size_t)h->lv[Lc].splane * sizeof(float), 0, (size_t)h->lv[Lc].plane * sizeof(float), B, s));
-    HIPC(h, hipMemsetAsync(h->errs, 0, (size_t)B * h->errstride * sizeof(u64), s));
-
-    SchedArgs SA = {};
-    MiscArgs MA = {};
-    IterQArgs IA = {};
-    size_t shmem = 0;
-    for (int l = 0; l < h->nlev; ++l) {
-        const Geom& g = h->lv[l];
-        SchedLevel& L = SA.lv[l];
-        L.w = g.w; L.h = g.h; L.pitch = g.pitch; L.plane = g.plane;
-        L.qx = (g.w + 3) / 4; L.ry = 256 / L.qx; if (L.ry < 1) L.ry = 1;
-        L.smax = g.h / (4 * L.ry) > 0 ? g.h / (4 * L.ry) : 1;
-        const float thr_f = (float)(P.epsilon * P.epsilon * (double)(g.w * g.h));
-        L.thr_q = (double)thr_f * 1073741824.0;
-        if (l > 0) { const Geom& gd = h->lv[l - 1]; L.up_sx = 1.0 / ((double)gd.w / g.w); L.up_sy = 1.0 / ((double)gd.h / g.h); }
-        const int LW = L.qx * 4 + 4;
-        const size_t sh = (size_t)(32 + 8 * L.ry * LW + 2 * (L.ry + 1) * LW + 2 * L.ry * L.qx) * sizeof(float);
-        if (sh > shmem) shmem = sh;
-        MA.lv[l] = L; IA.lv[l] = L; MA.pyr[l] = h->pyr[l];
-    }
-    int slots = h->slots_override;
-    if (slots <= 0) {
-        const size_t key = shmem * 1024 + 4 + (1ull << 40);
-        auto f = h->slots_cache.find(key);
-        if (f == h->slots_cache.end()) {
-            int per_cu = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iter2_q, 256, shmem);
-            if (per_cu < 1) per_cu = 1;
-            f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
-        }
-        slots = f->second;
-    }
-    SA.st = h->sc_st; SA.B = B; SA.err = h->errs; SA.errstride = h->errstride; SA.iters = h->iters_dev;
-    SA.nlev = h->nlev; SA.warps = P.warps; SA.inner = P.inner_iterations; SA.total = total; SA.median_on = P.median_filtering > 1 ? 1 : 0;
-    SA.slots = slots; SA.cnt = h->sc_cnt; SA.iter_items = h->sc_items; SA.iter_cap = h->sc_items_cap;
-    SA.misc_pair = h->sc_mpair; SA.misc_pref = h->sc_mpref;
-    MA.st = h->sc_st; MA.cnt = h->sc_cnt; MA.misc_pair = h->sc_mpair; MA.misc_pref = h->sc_mpref; MA.sb = h->sb;
-    MA.off0 = off0; MA.off1 = off1; MA.tab = h->tab; MA.wx = h->cwx; MA.wy = h->cwy; MA.rho = h->crho; MA.splane = h->lv[0].plane;
-    MA.up_mul = (float)(1 / P.scale_step); MA.out_scale = scale; MA.out = dflow;
-    IA.a.wx = h->cwx; IA.a.wy = h->cwy; IA.a.rho = h->crho; IA.a.sb = h->sb; IA.a.ctl = h->ctl; IA.a.err = h->errs;
-    IA.a.errstride = h->errstride; IA.a.thr_q = 0; IA.a.host_slot = nullptr; IA.a.B = B;
-    IA.a.l_t = (float)(P.lambda * P.theta); IA.a.theta = (float)P.theta; IA.a.taut = (float)(P.tau / P.theta);
-    IA.st = h->sc_st; IA.cnt = h->sc_cnt; IA.items = h->sc_items; IA.splane = h->lv[0].plane;
-
-    const bool overlap = h->sched_overlap != 0;
-    if (overlap && !h->misc_stream) {
-        HIPC(h, hipStreamCreateWithFlags(&h->misc_stream, hipStreamNonBlocking));
-        for (auto& e : h->sc_ev) HIPC(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    const int sched_threads = (B + 63) / 64 * 64;
-    const int iter_grid = (slots > B ? slots : B) + B + 64 < h->sc_items_cap ? (slots > B ? slots : B) + B + 64 : h->sc_items_cap;
-    const int misc_grid = h->num_cus * (h->misc_blocks_per_cu > 0 ? h->misc_blocks_per_cu : 8);
-    const int max_ss = h->sc_work_cap;
-    const int lag = h->sched_lag > 0 ? h->sched_lag : 1;
-    const unsigned seq0 = h->launch_seq;
-    unsigned checked = seq0;
-    bool stop = false;
-    int ss = 0;
-    std::vector<ProfEv*> iter_ev;
-    for (; ss < max_ss && !stop; ++ss) {
-        const unsigned q = h->launch_seq++;
-        h->slots_host[q % SLOT_RING] = -1;
-        SA.first = ss == 0; SA.ss = ss; SA.host_slot = h->slots_dev + q % SLOT_RING;
-        SA.work = h->profile ? h->sc_work : nullptr;
-        ProfEv *e0 = nullptr, *e1 = nullptr, *e2 = nullptr;
-        if (h->profile) {
-            e0 = prof_next(h); e1 = prof_next(h); e2 = prof_next(h);
-            if (!e0 || !e1 || !e2) return fail(h, TF_ERR_HIP, "hipEventCreate failed");
-            e0->level = -2; e1->level = -3; e2->level = -1; e2->it = ss;     // -2 k_sched, -3 k_misc_q, -1 k_iter2_q
-            HIPC(h, hipEventRecord(e0->a, s));
-        }
-        hipLaunchKernelGGL(k_sched, dim3(1), dim3(sched_threads), 0, s, SA);
-        if (h->profile) HIPC(h, hipEventRecord(e0->b, s));
-        hipStream_t ms = s;
-        if (overlap) {       // fork: the tile kernel of this super-step runs beside the iteration kernel
-            ms = h->misc_stream;
-            HIPC(h, hipEventRecord(h->sc_ev[(2 * ss) & 15], s));
-            HIPC(h, hipStreamWaitEvent(ms, h->sc_ev[(2 * ss) & 15], 0));
-        }
-        if (h->profile) HIPC(h, hipEventRecord(e1->a, ms));
-        if (P.median_filtering == 5) hipLaunchKernelGGL(k_misc_q<5>, dim3(misc_grid), dim3(256), 0, ms, MA);
-        else if (P.median_filtering == 3) hipLaunchKernelGGL(k_misc_q<3>, dim3(misc_grid), dim3(256), 0, ms, MA);
-        else hipLaunchKernelGGL(k_misc_q<1>, dim3(misc_grid), dim3(256), 0, ms, MA);
-        if (h->profile) { HIPC(h, hipEventRecord(e1->b, ms)); HIPC(h, hipEventRecord(e2->a, s)); }
-        hipLaunchKernelGGL(k_iter2_q, dim3(iter_grid), dim3(256), shmem, s, IA);
-        if (h->profile) HIPC(h, hipEventRecord(e2->b, s));
-        if (overlap) {       // join: the next k_sched reads what both kernels wrote
-            HIPC(h, hipEventRecord(h->sc_ev[(2 * ss + 1) & 15], ms));
-            HIPC(h, hipStreamWaitEvent(s, h->sc_ev[(2 * ss + 1) & 15], 0));
-        }
-        ++h->iter_launches;
-        while (checked <= q) {
-            int v = h->slots_host[checked % SLOT_RING];
-            if (v < 0) {
-                if (q - checked < (unsigned)lag) break;              // not there yet, and we may still run ahead
-                const double t0 = now_ms();
-                while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
-                    if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "super-step %u never reported (GPU hang?)", checked - seq0);
-                    if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
-                        return fail(h, TF_ERR_HIP, "stream drained but super-step %u did not report", checked - seq0);
-                }
-            }
-            ++checked;
-            if (v == 0) { stop = true; break; }
-        }
-    }
-    if (!stop) {
-        // the bound on super-steps was reached with the reports still outstanding: read the rest before judging
-        HIPC(h, hipStreamSynchronize(s));
-        for (; checked < h->launch_seq; ++checked)
-            if (h->slots_host[checked % SLOT_RING] == 0) { stop = true; break; }
-        if (!stop) return fail(h, TF_ERR_HIP, "scheduler did not finish within %d super-steps", max_ss);
-    }
-    if (h->profile) {
-        h->sc_work_host.assign((size_t)ss, 0.0);
-        HIPC(h, hipMemcpyAsync(h->sc_work_host.data(), h->sc_work, (size_t)ss * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
     HIPC(h, hipGetLastError());
     return TF_OK;
 }
@@ -1108,7 +855,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         if (overlap && kb >= 2) HIPC(h, hipStreamWaitEvent(h->stream, h->cev[2 + (kb & 1)], 0));   // that half's last copy-out
         HIPC(h, hipEventRecord(h->ev[1], h->stream));
         rc = deep ? df_solve_resident(h, dfr, F, nb, off0, off1, scale, dfl)
-                  : (sched_ok(h, nb) ? solve_resident_sched(h, dfr, F, nb, off0, off1, scale, dfl) : solve_resident(h, dfr, F, nb, off0, off1, scale, dfl));
+                  : solve_resident(h, dfr, F, nb, off0, off1, scale, dfl);
         if (rc) return rc;
         HIPC(h, hipEventRecord(h->ev[2], h->stream));
         if (overlap) {
@@ -1140,21 +887,18 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
                           &st->inner_iters_total, &st->outer_iters_total);
         st->iter_pair_steps = st->inner_iters_total;
         double ims = 0;
-        h->misc_ms = h->sched_ms = h->warp_ms = h->median_ms = 0;
+        h->warp_ms = h->median_ms = 0;
         for (size_t i = 0; i < h->prof_used; ++i) {
             float t = 0;
             ProfEv& pe = h->prof_pool[i];
             HIPC(h, hipEventElapsedTime(&t, pe.a, pe.b));
             pe.ms = t;
-            if (pe.level == -2) h->sched_ms += t;
-            else if (pe.level == -3) h->misc_ms += t;
-            else if (pe.level == -4) h->warp_ms += t;
+            if (pe.level == -4) h->warp_ms += t;
             else if (pe.level == -5) h->median_ms += t;
             else ims += t;
-            if (pe.level == -1 && (size_t)pe.it < h->sc_work_host.size()) pe.work = h->sc_work_host[(size_t)pe.it];
         }
         st->iter_ms = ims;
-        st->ms_warp = h->warp_ms; st->ms_median = h->median_ms; st->ms_misc = h->misc_ms; st->ms_sched = h->sched_ms;
+        st->ms_warp = h->warp_ms; st->ms_median = h->median_ms; st->ms_misc = 0; st->ms_sched = 0;
         st->ms_total = now_ms() - t0;
     }
     return TF_OK;
@@ -1171,7 +915,6 @@ int calc_common_guarded(tf_handle* h, Mode mode, const uint8_t* in0, const uint8
     if (rc != TF_OK && h) {
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-        if (h->misc_stream) (void)hipStreamSynchronize(h->misc_stream);
         (void)hipGetLastError();
     }
     return rc;
@@ -1200,11 +943,10 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->iter3_min_w = h->iter3_min_w; t->lds_pad_kb = h->lds_pad_kb;
+        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->tile_max_w = h->tile_max_w;
-        t->sched = h->sched; t->sched_min_pairs = h->sched_min_pairs; t->sched_lag = h->sched_lag; t->misc_blocks_per_cu = h->misc_blocks_per_cu; t->sched_overlap = h->sched_overlap;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1334,10 +1076,6 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
         return bail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter3_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter2_q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute");
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     {
         void* hp = nullptr; void* dp = nullptr;
@@ -1380,8 +1118,6 @@ TF_API void tf_destroy(tf_handle* h)
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& pe : h->prof_pool) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->misc_stream) (void)hipStreamDestroy(h->misc_stream);
-    for (auto& e : h->sc_ev) if (e) (void)hipEventDestroy(e);
     (void)tf_comm_destroy(h);
     for (auto& e : h->cev) if (e) (void)hipEventDestroy(e);
     if (h->wa) (void)hipFree(h->wa);
@@ -1458,7 +1194,6 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lag") h->lag = value < 0 ? DEFAULT_LAG : (value < SLOT_RING / 2 ? value : SLOT_RING / 2);   // 0 = wait for every launch's report (it is published at the launch's start); unread slots must never be overwritten
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
-    else if (n == "iter3_min_w") h->iter3_min_w = value;
     else if (n == "lds_pad_kb") h->lds_pad_kb = value < 0 ? 0 : value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
@@ -1472,11 +1207,6 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "df_fuse_ds") h->df_fuse_ds = value ? 1 : 0;
-    else if (n == "sched") h->sched = value;
-    else if (n == "sched_min_pairs") h->sched_min_pairs = value < 1 ? 1 : value;
-    else if (n == "sched_lag") h->sched_lag = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (n == "sched_overlap") h->sched_overlap = value;
-    else if (n == "misc_blocks") h->misc_blocks_per_cu = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
@@ -1498,10 +1228,10 @@ TF_API int tf_dbg_launch_profile(tf_handle* h, int* level, int* warp, int* it, f
     int n = 0;
     for (size_t i = 0; i < h->prof_used; ++i) {
         const ProfEv& pe = h->prof_pool[i];
-        if (pe.level < -1) continue;                       // k_sched / k_misc_q records of the scheduler path
+        if (pe.level < 0) continue;                        // warp / median records
         if (n < max_n) {
             if (level) level[n] = pe.level;
-            if (warp) warp[n] = pe.level == -1 ? (int)(pe.work / 1024.0) : pe.warp;    // scheduler path: k px-iterations of the launch
+            if (warp) warp[n] = pe.warp;
             if (it) it[n] = pe.it;
             if (ms) ms[n] = pe.ms;
         }

@@ -174,17 +174,60 @@ def read_study(path):
         import pydicom
     except ImportError as e:
         raise DICOMReadError(f"Failed to read DICOM file: {path} (pydicom is not installed)") from e
-    ds = pydicom.dcmread(path)
-    arr = ds.pixel_array
-    md = {"pixel_spacing": None, "frame_rate": None, "R_wave_data_present": False, "R_times": None}
     try:
-        md["pixel_spacing"] = float(ds.SequenceOfUltrasoundRegions[0].PhysicalDeltaX)
-    except Exception:
+        ds = pydicom.dcmread(path)
+        arr = ds.pixel_array
+    except (IOError, OSError, KeyError, AttributeError) as e:             # reference _read_dicom_file (:307-312) -> DICOMReadError (:521-522)
+        raise DICOMReadError(f"Failed to read DICOM file: {path}") from e
+    return dicom_to_study(ds, arr, _pydicom_color_converter(pydicom))
+
+
+def _pydicom_color_converter(pydicom):
+    """The reference's colour-space step (calculate_optical_flow.py:524-526) as a callable (ds, arr) -> arr."""
+    def convert(ds, arr):
+        handlers = pydicom.pixel_data_handlers
+        if handlers.numpy_handler.should_change_PhotometricInterpretation_to_RGB(ds):
+            return handlers.convert_color_space(arr, ds.PhotometricInterpretation, "RGB")
+        return arr
+    return convert
+
+
+def extract_dicom_metadata(ds):
+    """The reference's _extract_dicom_metadata (calculate_optical_flow.py:315-365) on any dataset-like object, rule for rule:
+    pixel spacing = PhysicalDeltaX of the first ultrasound region (tag 0018,6011), R-wave times when RWaveTimeVector is
+    present and not a bare float, frame rate = CineRate as stored, else round(1000 / FrameTime), else
+    round(1000 / FrameTimeVector[1]).  The rounding matters: conversion_factor = pixel_spacing * frame_rate scales every
+    stored flow value (:538-541)."""
+    md = {"pixel_spacing": None, "frame_rate": None, "R_times": None, "R_wave_data_present": False}
+    try:
+        md["pixel_spacing"] = ds[0x0018, 0x6011][0]["PhysicalDeltaX"].value
+    except (KeyError, AttributeError, IndexError, TypeError):
         pass
-    for tag, f in (("CineRate", lambda v: float(v)), ("FrameTime", lambda v: 1000.0 / float(v))):
-        if md["frame_rate"] is None and hasattr(ds, tag):
-            md["frame_rate"] = f(getattr(ds, tag))
-    return arr, md, str(getattr(ds, "PatientID", "")), int(getattr(ds, "HeartRate", 0) or 0)
+    try:
+        if type(ds.RWaveTimeVector) != float and ds.RWaveTimeVector is not None:      # noqa: E721  (the reference's own test)
+            md["R_times"] = np.asarray(ds.RWaveTimeVector)
+            md["R_wave_data_present"] = True
+    except (AttributeError, KeyError, TypeError):
+        pass
+    try:
+        md["frame_rate"] = ds.CineRate
+    except (AttributeError, KeyError):
+        try:
+            md["frame_rate"] = np.round(1000 / float(ds.FrameTime))
+        except (AttributeError, KeyError, ValueError, ZeroDivisionError):
+            try:
+                md["frame_rate"] = np.round(1000 / float(ds.FrameTimeVector[1]))
+            except (AttributeError, KeyError, IndexError, ValueError, ZeroDivisionError):
+                pass
+    return md
+
+
+def dicom_to_study(ds, arr, convert_color=None):
+    """(frames, metadata, patient id, heart rate) of a read DICOM dataset, as process_video uses them (:524-531, :405-417):
+    colour space converted to RGB when the dataset asks for it, metadata per extract_dicom_metadata."""
+    if convert_color is not None:
+        arr = convert_color(ds, arr)
+    return arr, extract_dicom_metadata(ds), str(getattr(ds, "PatientID", "")), int(getattr(ds, "HeartRate", 0) or 0)
 
 
 def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, chunk_index=0, mode="RVIO_2class", bkgd_comp="none",

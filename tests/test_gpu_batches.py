@@ -1,9 +1,7 @@
-"""The free-running pair scheduler (csrc/teeflow_sched.hip.h) against the lock-step driver and the CPU oracle.
-
-Both drivers run the same device arithmetic; what differs is who decides when a pair moves on (one state machine per pair
-on the device instead of host-driven stages).  So the tests demand identical executed-iteration counts and bit-identical
-flows from the two, on batches where pairs stop at very different iterations, plus the oracle on a spread sample, and the
-BASELINE.json configs[2] per-GPU shard (128 pairs x 512^2 in one call)."""
+"""Large and uneven batches through the lock-step driver: pairs that stop at very different iterations (identical frames,
+unrelated frames, ordinary pairs) in one call, one lane against two, sequence mode with sub-batching, and the BASELINE.json
+configs[2] per-GPU shard (128 pairs x 512^2 in one call) -- identical executed-iteration counts and bit-identical flows
+against the CPU oracle on a spread sample."""
 import numpy as np
 import pytest
 
@@ -29,8 +27,7 @@ def _mixed_pairs(n, H, W, seed0=100):
     return np.stack(I0s), np.stack(I1s)
 
 
-def _run(eng, I0s, I1s, sched, lanes=1):
-    eng.set_tuning("sched", sched)
+def _run(eng, I0s, I1s, lanes=1):
     eng.set_tuning("lanes", lanes)
     f = np.array(eng.calc_pairs(I0s, I1s))
     return f, eng.last_iters().copy()
@@ -43,27 +40,28 @@ def _run(eng, I0s, I1s, sched, lanes=1):
     (36, 240, 320, {"median_filtering": 1, "inner_iterations": 6, "outer_iterations": 2, "epsilon": 0.05}),
     (48, 200, 200, {"lambda_": 0.05, "theta": 0.2, "tau": 0.2, "scale_step": 0.7, "nscales": 4}),
 ])
-def test_scheduler_equals_lockstep(n, H, W, params):
+def test_mixed_batch_one_lane_equals_two_and_the_oracle(oracle, n, H, W, params):
     I0s, I1s = _mixed_pairs(n, H, W)
     eng = _engine(n, **params)
     try:
-        f0, it0 = _run(eng, I0s, I1s, sched=0)
-        f1, it1 = _run(eng, I0s, I1s, sched=1)
-        assert np.array_equal(it0, it1), "executed iteration counts differ between the two drivers"
-        assert np.array_equal(f0, f1), f"{np.sum(f0 != f1)} flow values differ"
-        spread = it1[..., 0].sum(axis=(1, 2))
+        f0, it0 = _run(eng, I0s, I1s, lanes=1)
+        spread = it0[..., 0].sum(axis=(1, 2))
         assert spread.max() > 1.5 * spread.min(), "the batch should mix fast and slow pairs"
-        f2, it2 = _run(eng, I0s, I1s, sched=1, lanes=2)                     # two lanes, each with its own scheduler
+        f2, it2 = _run(eng, I0s, I1s, lanes=2)                               # the batch cut over two independent lanes
         assert np.array_equal(it0, it2) and np.array_equal(f0, f2)
+        op = oracle.default_params(**params)
+        for b in (3, 5, n - 1):                                              # a zero-flow pair, an unrelated pair, the last one
+            ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], op, return_iters=True)
+            assert np.array_equal(it0[b], ref_it[:nl]) and np.array_equal(f0[b], ref), f"pair {b}"
     finally:
         eng.close()
 
 
-def test_scheduler_matches_oracle_on_sample(oracle):
+def test_mixed_batch_matches_oracle_on_sample(oracle):
     I0s, I1s = _mixed_pairs(32, 256, 256, seed0=300)
     eng = _engine(32)
     try:
-        f, it = _run(eng, I0s, I1s, sched=1)
+        f, it = _run(eng, I0s, I1s)
         for b in (0, 3, 5, 17, 31):
             ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], return_iters=True)
             assert np.array_equal(it[b], ref_it[:nl]), f"pair {b}: iteration counts differ from the oracle"
@@ -72,13 +70,12 @@ def test_scheduler_matches_oracle_on_sample(oracle):
         eng.close()
 
 
-def test_scheduler_sequence_mode_and_sub_batches(oracle):
-    """tf_calc_seq (pairs share frames) through the scheduler, and a call larger than the engine's capacity."""
+def test_sequence_mode_and_sub_batches(oracle):
+    """tf_calc_seq (pairs share frames) with a call larger than the engine's capacity."""
     from tee_optical_flow_amd.synth import speckle_sequence
     frames = speckle_sequence(5, 70, 224, 224)
     eng = _engine(40)
     try:
-        eng.set_tuning("sched", 1)
         flows = np.array(eng.calc_batch(frames, scale=2.5))                  # 69 pairs > capacity 40: two sub-batches
         it = eng.last_iters()
         for i in (0, 39, 40, 68):

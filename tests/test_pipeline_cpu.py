@@ -93,3 +93,50 @@ def test_process_video_otsu_end_to_end_on_cpu_double(oracle):
     out_flip = process_video(None, None, None, verbose=False, mode="otsu", no_saliency=True, flipLR=True, nparr=nparr,
                              metadata=md, flow_model=OracleModel(oracle))
     assert out_flip.shape == out.shape and not np.array_equal(out_flip, out)
+
+
+class _Elem:
+    def __init__(self, value):
+        self.value = value
+
+
+class _StubDS:
+    """A pydicom-Dataset-shaped object: attribute access for keywords, [group, element] access for tags."""
+    def __init__(self, tags=None, **kw):
+        self._tags = tags or {}
+        self.__dict__.update(kw)
+
+    def __getitem__(self, key):
+        return self._tags[key]
+
+
+def test_dicom_metadata_follows_the_reference_rule_for_rule():
+    """the .dcm branch must mirror _extract_dicom_metadata / the colour-space step of the reference
+    (calculate_optical_flow.py:315-365, 524-526).  pydicom is absent here, so the rules run on a stub dataset."""
+    from tee_optical_flow_amd.pipeline import dicom_to_study, extract_dicom_metadata
+    region = [{"PhysicalDeltaX": _Elem(0.0321)}]
+    # CineRate wins and is taken as stored (no rounding, no float())
+    md = extract_dicom_metadata(_StubDS({(0x0018, 0x6011): region}, CineRate=30, FrameTime="33.333", RWaveTimeVector=[12.0, 845.5]))
+    assert md["pixel_spacing"] == 0.0321 and md["frame_rate"] == 30 and md["R_wave_data_present"] is True
+    assert isinstance(md["R_times"], np.ndarray) and md["R_times"].tolist() == [12.0, 845.5]
+    # no CineRate: round(1000 / FrameTime) -- 1000 / 33.333 = 30.0003 -> 30.0; unrounded it would change every stored flow value
+    md = extract_dicom_metadata(_StubDS({(0x0018, 0x6011): region}, FrameTime="33.333"))
+    assert md["frame_rate"] == 30.0 and md["frame_rate"] == np.round(1000 / 33.333) and md["R_wave_data_present"] is False and md["R_times"] is None
+    md = extract_dicom_metadata(_StubDS(FrameTime="21.7"))
+    assert md["frame_rate"] == 46.0 and md["pixel_spacing"] is None
+    # neither: round(1000 / FrameTimeVector[1])
+    md = extract_dicom_metadata(_StubDS(FrameTimeVector=[0.0, 16.6, 16.6]))
+    assert md["frame_rate"] == 60.0
+    # FrameTime present but unusable (zero) falls through to the vector; nothing usable -> None (conversion factor 1.0 downstream)
+    assert extract_dicom_metadata(_StubDS(FrameTime="0", FrameTimeVector=[0.0, 20.0]))["frame_rate"] == 50.0
+    assert extract_dicom_metadata(_StubDS())["frame_rate"] is None
+    # a bare float RWaveTimeVector is "not present" (the reference's own test), None likewise
+    assert extract_dicom_metadata(_StubDS(RWaveTimeVector=3.5))["R_wave_data_present"] is False
+    assert extract_dicom_metadata(_StubDS(RWaveTimeVector=None))["R_wave_data_present"] is False
+    # the colour-space step runs before anything else sees the frames
+    arr = np.zeros((2, 4, 4, 3), np.uint8)
+    seen = []
+    out, md, pid, hr = dicom_to_study(_StubDS(PatientID="P7", HeartRate=71, CineRate=25), arr, lambda ds, a: (seen.append(ds.PatientID), a + 1)[1])
+    assert seen == ["P7"] and (out == 1).all() and pid == "P7" and hr == 71 and md["frame_rate"] == 25
+    out, md, pid, hr = dicom_to_study(_StubDS(), arr)
+    assert out is arr and pid == "" and hr == 0
