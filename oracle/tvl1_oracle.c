@@ -478,15 +478,17 @@ static void proc_one_scale(const orc_params* P, const float* I0, const float* I1
         /* cudaoptflow tvl1flow.cpp procOneScale: one loop, error only on odd iterations once prevError < threshold */
         orc_warp_cuda(I0, I1, B->I1x, B->I1y, u1, u2, w, h, B->I1wx, B->I1wy, B->grad, B->rho_c);
         const int iterations = P->inner_iterations * P->outer_iterations;
-        float error = FLT_MAX, prevError = 0.0f;
+        /* scaledEpsilon, error and prevError are doubles in the CUDA class (the CPU class keeps a float scaledEpsilon) */
+        const double scaledEps = P->epsilon * P->epsilon * (double)(w * h);
+        double error = DBL_MAX, prevError = 0.0;
         int n = 0;
-        for (; error > scaledEpsilon && n < iterations; ++n) {
-            const int calcError = P->epsilon > 0 && (n & 1) && prevError < scaledEpsilon;
+        for (; error > scaledEps && n < iterations; ++n) {
+            const int calcError = P->epsilon > 0 && (n & 1) && prevError < scaledEps;
             const double e = iterate_once(B->I1wx, B->I1wy, B->grad, B->rho_c, u1, u2, u3, B->p11, B->p12, B->p21, B->p22,
                                           B->p31, B->p32, B->v1, B->v2, B->v3, B->div1, B->div2, B->div3, w, h,
                                           l_t, (float)P->theta, taut, (float)P->gamma, P->err_mode, NULL);
-            if (calcError) { error = (float)e; prevError = error; }
-            else { error = FLT_MAX; prevError -= scaledEpsilon; }
+            if (calcError) { error = e; prevError = error; }
+            else { error = DBL_MAX; prevError -= scaledEps; }
         }
         if (n_inner_out) n_inner_out[wi] = n;
         if (n_outer_out) n_outer_out[wi] = 0;

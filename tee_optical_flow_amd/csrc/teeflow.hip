@@ -402,6 +402,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     const int inner = P.inner_iterations, total = P.inner_iterations * P.outer_iterations;
     const float thr_f = (float)(P.epsilon * P.epsilon * (double)(g.w * g.h));
     const double thr_q = (double)thr_f * 1073741824.0;
+    const double thr_d = P.epsilon * P.epsilon * (double)(g.w * g.h);     // TF_VARIANT_CUDA compares in double
     hipStream_t s = h->stream;
 
     WarpArgs wa;
@@ -421,7 +422,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     ia.wx = h->cwx; ia.wy = h->cwy; ia.rho = h->crho; ia.sb = h->sb; ia.ctl = h->ctl; ia.err = h->errs;
     ia.errstride = h->errstride; ia.thr_q = thr_q; ia.g = g;
     ia.l_t = (float)(P.lambda * P.theta); ia.theta = (float)P.theta; ia.taut = (float)(P.tau / P.theta);
-    ia.variant = P.variant; ia.thr_f = thr_f;
+    ia.variant = P.variant; ia.thr_d = thr_d;
     const bool cuda_variant = P.variant == TF_VARIANT_CUDA;      // one loop, no median, stops only after odd iterations
     MedArgs ma;
     ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
@@ -487,7 +488,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
             }
         }
         hipLaunchKernelGGL(k_stage_end2, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
-                           total, inner, (P.median_filtering > 1 && !cuda_variant) ? 1 : 0, thr_q, l, wi, h->nlev, P.warps, P.variant, thr_f);
+                           total, inner, (P.median_filtering > 1 && !cuda_variant) ? 1 : 0, thr_q, l, wi, h->nlev, P.warps, P.variant, thr_d);
         return TF_OK;
     }
     int utog = 0, ptog = 0;

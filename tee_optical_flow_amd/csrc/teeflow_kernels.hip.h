@@ -583,7 +583,7 @@ struct IterArgs {
     int* host_slot;   // host-mapped word: block 0 publishes how many pairs are still iterating at this launch
     int B;
     int variant;      // 0 = cv2.optflow CPU DualTVL1; 1 = cv2.cuda.OpticalFlowDual_TVL1 stop rule
-    float thr_f;      // epsilon^2 * area as the float upstream compares with (variant 1)
+    double thr_d;     // epsilon^2 * area in double: the CUDA class keeps scaledEpsilon, error and prevError in double (variant 1)
 };
 
 // Block 0 / wave 0 tells the host how many of the B pairs enter iteration `it` active, through fine-grained
@@ -1115,13 +1115,15 @@ __device__ __forceinline__ int pair_mode2(const u64* e, int it, int total, doubl
 // threshold.  A stop can therefore only follow an odd iteration = the second one of a launch: no REPLAY in this variant.
 // Replays the recurrence over iterations [0, it): M_NORMAL if the pair still iterates at launch `it`, else M_EXIT with
 // *n_it = iterations executed.
-__device__ __forceinline__ int pair_mode_cuda(const u64* e, int it, int total, float thr, int* n_it)
+__device__ __forceinline__ int pair_mode_cuda(const u64* e, int it, int total, double thr, int* n_it)
 {
-    float prev = 0.0f;
+    // cudaoptflow procOneScale keeps scaledEpsilon / error / prevError in double ([UPSTREAM-FROM-MEMORY]; a float
+    // `prevError -= scaledEpsilon` could flip the iteration at which the sum is next consulted)
+    double prev = 0.0;
     for (int n = 0; n < it; ++n) {
-        const bool calc = thr > 0.0f && (n & 1) && prev < thr;
+        const bool calc = thr > 0.0 && (n & 1) && prev < thr;
         if (calc) {
-            const float err = (float)((double)e[n] * 0x1p-30);
+            const double err = (double)e[n] * 0x1p-30;
             prev = err;
             if (!(err > thr)) { if (n_it) *n_it = n + 1; return M_EXIT; }
         } else prev -= thr;
@@ -1130,9 +1132,9 @@ __device__ __forceinline__ int pair_mode_cuda(const u64* e, int it, int total, f
     return it < total ? M_NORMAL : M_EXIT;
 }
 
-__device__ __forceinline__ int pair_mode(const u64* e, int it, int total, double thr_q, int variant, float thr_f)
+__device__ __forceinline__ int pair_mode(const u64* e, int it, int total, double thr_q, int variant, double thr_d)
 {
-    return variant ? pair_mode_cuda(e, it, total, thr_f, nullptr) : pair_mode2(e, it, total, thr_q);
+    return variant ? pair_mode_cuda(e, it, total, thr_d, nullptr) : pair_mode2(e, it, total, thr_q);
 }
 
 // Work items of a tvl1_iter launch when the strips are sized ON THE DEVICE from the number of pairs that still
@@ -1164,7 +1166,7 @@ __device__ __forceinline__ void publish_active_count2(const Iter2Args& A)
     if (a.host_slot && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
         int c = 0;
         for (int b2 = threadIdx.x; b2 < a.B; b2 += 64)
-            c += pair_mode(a.err + (size_t)b2 * a.errstride, a.it, A.total, a.thr_q, a.variant, a.thr_f) != M_EXIT ? 1 : 0;
+            c += pair_mode(a.err + (size_t)b2 * a.errstride, a.it, A.total, a.thr_q, a.variant, a.thr_d) != M_EXIT ? 1 : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
         if (threadIdx.x == 0) __hip_atomic_store(a.host_slot, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         const int nchunk = (a.B + 63) >> 6, nw = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
         for (int c = wv; c < nchunk; c += nw) {
             const int pb = c * 64 + ln;
-            const bool on = pb < a.B && pair_mode(a.err + (size_t)pb * a.errstride, a.it, A.total, a.thr_q, a.variant, a.thr_f) != M_EXIT;
+            const bool on = pb < a.B && pair_mode(a.err + (size_t)pb * a.errstride, a.it, A.total, a.thr_q, a.variant, a.thr_d) != M_EXIT;
             const u64 m = __ballot(on);
             if (ln == 0) sred[c] = m;
         }
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(512) void k_iter2_rows(Iter2Args A, int R, int QX, 
         __syncthreads();                                    // sred is reused for the error sums below
     }
     u64* errb = a.err + (size_t)b * a.errstride;
-    const int mode = pair_mode(errb, a.it, A.total, a.thr_q, a.variant, a.thr_f);   // block-uniform
+    const int mode = pair_mode(errb, a.it, A.total, a.thr_q, a.variant, a.thr_d);   // block-uniform
     if (mode == M_EXIT) return;
     const bool replay = mode == M_REPLAY;
     const PairCtl c = a.ctl[b];
@@ -1500,7 +1502,7 @@ __global__ __launch_bounds__(256) void k_iter2_tile(Iter2Args A)
     publish_active_count2(A);
     const int b = blockIdx.z;
     u64* errb = a.err + (size_t)b * a.errstride;
-    const int mode = pair_mode(errb, a.it, A.total, a.thr_q, a.variant, a.thr_f);   // block-uniform
+    const int mode = pair_mode(errb, a.it, A.total, a.thr_q, a.variant, a.thr_d);   // block-uniform
     if (mode == M_EXIT) return;
     const bool replay = mode == M_REPLAY;
     const PairCtl c = a.ctl[b];
@@ -1656,13 +1658,13 @@ __global__ __launch_bounds__(256) void k_median2(MedArgs a, int total)
 // stage end for the two-iterations-per-launch schedule: a pair took part in ceil(n_it/2) launches
 __global__ void k_stage_end2(const u64* __restrict__ err, int errstride, PairCtl* ctl, int* iters, int B,
                              int total, int inner, int median_on, double thr_q, int level, int warp, int nlev, int warps,
-                             int variant, float thr_f)
+                             int variant, double thr_d)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const u64* e = err + (size_t)b * errstride;
     int n_it = total;
-    if (variant) (void)pair_mode_cuda(e, total, total, thr_f, &n_it);
+    if (variant) (void)pair_mode_cuda(e, total, total, thr_d, &n_it);
     else
         for (int j = 0; j < total; ++j)
             if (!((double)e[j] > thr_q)) { n_it = j + 1; break; }

@@ -68,6 +68,9 @@ def _all_gather(local, world, group, engine=None):
     local = local.contiguous()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if engine is not None and local.is_cuda and getattr(engine, "has_comm", False):
+        # The library orders its communication stream behind the ENGINE's stream only.  `local` may also carry work of torch's
+        # current stream (the zero fill of a short or empty shard, anything a caller computed with torch ops): finish that first.
+        torch.cuda.current_stream(local.device).synchronize()
         engine.comm_wait(engine.allgather(local.data_ptr(), local.numel(), out.data_ptr()))
         return out
     dist.all_gather_into_tensor(out, local, group=group)

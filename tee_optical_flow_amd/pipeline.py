@@ -28,9 +28,10 @@ logger = logging.getLogger(__name__)
 
 def make_flow_model(OF_algo="TVL1", config=None, device_id=0, tvl1_variant="cpu"):
     """Reference :564-578.  tvl1_variant='cpu' (default, the parity target) is the reference's non-CUDA branch:
-    createOptFlow_DualTVL1() + setLambda(config.lambda_value) (:577-578).  tvl1_variant='cuda' reproduces what the reference
-    runs on a CUDA box (:572-575): cv2.cuda.OpticalFlowDual_TVL1.create() with NOTHING set on it -- lambda_value is
-    silently ignored there, and so it is here."""
+    createOptFlow_DualTVL1() + setLambda(config.lambda_value) (:577-578).  tvl1_variant='cuda' APPROXIMATES what the
+    reference runs on a CUDA box (:572-575): cv2.cuda.OpticalFlowDual_TVL1.create() with NOTHING set on it -- lambda_value is
+    silently ignored there, and so it is here.  Parity of that variant is unpinned: it restates
+    the CUDA class's four known differences from memory, not cuda::resize's sampling or nvcc's FMA contraction."""
     if config is None:
         config = default_optical_flow_config()
     if OF_algo == "TVL1":
