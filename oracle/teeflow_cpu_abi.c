@@ -61,6 +61,7 @@ static int validate(tf_handle* h, const tf_params* p)
     if (p->gamma != 0.0) return fail(h, TF_ERR_UNSUPPORTED, "gamma != 0 is not implemented");
     if (p->use_initial_flow) return fail(h, TF_ERR_UNSUPPORTED, "useInitialFlow is not implemented");
     if (!(p->scale_step > 0.0 && p->scale_step < 1.0)) return fail(h, TF_ERR_INVALID_ARG, "scaleStep must be in (0,1)");
+    if (p->scale_step == 0.5) return fail(h, TF_ERR_UNSUPPORTED, "scaleStep == 0.5: cv::resize's INTER_AREA fast path is not restated");
     if (!(p->theta > 0.0) || !(p->tau > 0.0) || !(p->lambda > 0.0) || !(p->epsilon >= 0.0)) return fail(h, TF_ERR_INVALID_ARG, "tau, lambda, theta must be > 0 and epsilon >= 0");
     if (p->variant != TF_VARIANT_CPU && p->variant != TF_VARIANT_CUDA) return fail(h, TF_ERR_INVALID_ARG, "bad variant");
     if (p->variant == TF_VARIANT_CUDA && (p->inner_iterations * p->outer_iterations) % 2) return fail(h, TF_ERR_UNSUPPORTED, "TF_VARIANT_CUDA needs an even iteration count");

@@ -190,6 +190,10 @@ int validate_params(tf_handle* h, const tf_params& p)
         return fail(h, TF_ERR_UNSUPPORTED, "TF_VARIANT_CUDA needs an even iteration count (inner*outer), got %d", p.inner_iterations * p.outer_iterations);
     if (p.use_initial_flow) return fail(h, TF_ERR_UNSUPPORTED, "useInitialFlow is not implemented");
     if (!(p.scale_step > 0.0 && p.scale_step < 1.0)) return fail(h, TF_ERR_INVALID_ARG, "scaleStep must be in (0,1), got %g", p.scale_step);
+    // cv::resize silently runs INTER_AREA instead of INTER_LINEAR when both scale factors are exactly 2 (imgproc/resize.cpp, "in
+    // case of scale_x && scale_y is equal to 2"): same value mathematically, not the same float as the bilinear form k_pyr_down
+    // computes.  That branch is not restated, so the one scaleStep that takes it is refused rather than silently different.
+    if (p.scale_step == 0.5) return fail(h, TF_ERR_UNSUPPORTED, "scaleStep == 0.5 makes cv::resize take its INTER_AREA fast path for the pyramid, which is not implemented");
     if (!(p.theta > 0.0) || !(p.tau > 0.0) || !(p.lambda > 0.0) || !(p.epsilon >= 0.0))
         return fail(h, TF_ERR_INVALID_ARG, "tau, lambda, theta must be > 0 and epsilon >= 0");
     return TF_OK;

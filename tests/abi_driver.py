@@ -50,6 +50,7 @@ def drive(L, frames, pairs):
     codes.append(L.tf_set_param(h, _lib.PARAM_KEYS["median_filtering"], 4.0))        # not 1/3/5 -> TF_ERR_UNSUPPORTED
     codes.append(L.tf_set_param(h, _lib.PARAM_KEYS["gamma"], 0.5))                   # unsupported
     codes.append(L.tf_set_param(h, _lib.PARAM_KEYS["scale_step"], 1.5))              # invalid
+    codes.append(L.tf_set_param(h, _lib.PARAM_KEYS["scale_step"], 0.5))              # cv::resize's INTER_AREA fast path: not restated -> UNSUPPORTED
     codes.append(L.tf_set_param(h, 99, 1.0))                                         # unknown key
     codes.append(L.tf_calc_pair(h, None, None, 8, 8, None, None))                    # null pointers
     v = C.c_double()

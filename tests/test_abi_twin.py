@@ -20,7 +20,7 @@ def cpu_run(oracle):
 def test_checker_library_speaks_the_abi(cpu_run, oracle):
     out, frames, (I0s, I1s) = cpu_run
     assert out["abi"] == 2
-    assert out["codes"] == [0, 2, 2, 1, 1, 1] and out["median_after_bad_set"] == 5.0      # TF_OK, UNSUPPORTED x2, INVALID_ARG x3
+    assert out["codes"] == [0, 2, 2, 1, 2, 1, 1] and out["median_after_bad_set"] == 5.0   # TF_OK, UNSUPPORTED x2, INVALID_ARG, UNSUPPORTED (scaleStep 0.5), INVALID_ARG x2
     assert out["seq_too_short"] == 1 and out["bad_variant"] == 1 and out["deepflow_set_param"] == 2
     ref, it, nl = oracle.tvl1_calc(I0s[0], I1s[0], return_iters=True)
     assert np.array_equal(out["pair_flow"], ref) and out["pair_stats"][:3] == (1, nl, 5)

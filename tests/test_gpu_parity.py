@@ -83,7 +83,7 @@ def test_sub_batching_when_batch_exceeds_capacity(oracle):
 
 @pytest.mark.parametrize("params", [dict(lambda_=0.05), dict(median_filtering=3), dict(median_filtering=1),
                                     dict(nscales=3, warps=2), dict(inner_iterations=7, outer_iterations=3),
-                                    dict(epsilon=0.05, tau=0.2, theta=0.25), dict(scale_step=0.5)])
+                                    dict(epsilon=0.05, tau=0.2, theta=0.25), dict(scale_step=0.55)])
 def test_non_default_parameters_match_oracle(oracle, params):
     import tee_optical_flow_amd as T
     from tee_optical_flow_amd.synth import speckle_pair

@@ -24,7 +24,7 @@ def main():
         p = dict(tau=float(rng.choice([0.25, 0.2, 0.1])), lambda_=float(rng.choice([0.15, 0.05, 0.3, 1.0])),
                  theta=float(rng.choice([0.3, 0.2, 0.5])), nscales=int(rng.integers(1, 7)), warps=int(rng.integers(1, 6)),
                  epsilon=float(rng.choice([0.01, 0.02, 0.005, 0.05])), inner_iterations=int(rng.choice([30, 10, 7, 2, 1, 16, 9, 3, 12])),
-                 outer_iterations=int(rng.choice([10, 1, 3, 5])), scale_step=float(rng.choice([0.8, 0.5, 0.7, 0.9])),
+                 outer_iterations=int(rng.choice([10, 1, 3, 5])), scale_step=float(rng.choice([0.8, 0.55, 0.7, 0.9])),
                  median_filtering=int(rng.choice([5, 3, 1])))
         variant = "cuda" if rng.random() < 0.25 else "cpu"        # TF_VARIANT_CUDA needs an even iteration count
         if variant == "cuda" and (p["inner_iterations"] * p["outer_iterations"]) % 2:
