@@ -37,11 +37,58 @@ HBM_STREAM_GBS = 6290.0
 SIMDS = 256 * 4         # 256 CUs x 4 SIMDs
 TVL1_KERNEL = "k_iter2_rows"
 DF_KERNEL = "k_df_sor_rt"
-# FETCH_SIZE correction (MI355X_MICROARCH.md, HBM): gfx950 tallies the 128-B requests of 16-B-per-lane loads at 64 B, so
-# k_iter2_rows (dwordx4 loads) doubles the counter.  k_df_sor_rt stages its tiles with 8-B-per-lane loads, a width the
-# guide leaves uncalibrated; doubling its count would exceed every byte the kernel requests (8 planes x 4 B x 1.875 halo =
-# 60 B per tile pixel and launch), while the raw count sits between that and the halo-free 32 B -- so it is taken as is.
-FETCH_FACTOR = {"TVL1": 2.0, "deepflow": 1.0}
+# FETCH_SIZE correction.  MI355X_MICROARCH.md (HBM): gfx950 tallies the 128-B requests of 16-B-per-lane loads at 64 B, "other
+# widths: calibrate".  Calibrated (tools/calibrate_fetch.sh -> profiles/r03_fetch_calibration.json: 1-GiB streaming copies under
+# --pmc): the counter reports half the bytes at EVERY width tried -- 4, 8, 16 B per lane and the SOR kernel's 8-B tile-row
+# shape -- and WRITE_SIZE is exact.  Round 2 took the 8-B loads of the DeepFlow kernel raw (factor 1): its read traffic was
+# under-reported by 2x.
+LOAD_BYTES_PER_LANE = {"TVL1": "16", "deepflow": "8_tile_rows"}
+
+
+def fetch_factor(algo):
+    """(factor, source) for FETCH_SIZE of the dominant kernel's load shape, from the newest calibration under profiles/."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fetch_calibration.json")))
+    if files:
+        try:
+            with open(files[-1]) as f:
+                k = json.load(f)["kernels"][LOAD_BYTES_PER_LANE[algo]]
+            return float(round(k["fetch_factor"], 3)), f"profiles/{os.path.basename(files[-1])} [{LOAD_BYTES_PER_LANE[algo]} B per lane]"
+        except (OSError, ValueError, KeyError):
+            pass
+    return 2.0, "MI355X_MICROARCH.md (16-B-per-lane streaming reads); no calibration file under profiles/"
+
+
+def classify_limiter(kernel, frac_of_streaming_ceiling):
+    """What the stored SQ / GRBM counter passes of THIS build (profiles/*_sq_counters.json, source fingerprint checked) say limits
+    the dominant kernel, next to the measured share of the streaming ceiling.  Returns (limiter string, evidence dict)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                rec = json.load(fh).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if not rec or "derived" not in rec:
+            continue
+        if rec.get("source_fingerprint") not in (None, kernel_source_fingerprint()):
+            continue
+        d = rec["derived"]
+        busy, parked, stalled = d.get("valu_pipe_busy_per_simd_all_launches"), d.get("wave_time_share_parked_waitcnt_or_barrier"), d.get("wave_time_share_issue_stalled")
+        ev = {"source": f"profiles/{os.path.basename(f)}", "source_fingerprint": rec.get("source_fingerprint"), "valu_pipe_busy_per_simd": busy,
+              "wave_time_parked_on_waitcnt_or_barrier": parked, "wave_time_issue_stalled": stalled,
+              "mean_waves_per_simd_resident": d.get("mean_waves_per_simd_resident"), "frac_of_streaming_ceiling": frac_of_streaming_ceiling}
+        if rec.get("source_fingerprint") is None:
+            ev["note"] = "counter record carries no source fingerprint (taken before round 3): it may describe an older build of this kernel"
+        if busy is not None and busy >= 0.8:
+            lim = "valu (vector ALU busy %.2f of the time)" % busy
+        elif frac_of_streaming_ceiling is not None and frac_of_streaming_ceiling >= 0.8:
+            lim = "hbm (%.2f of the streaming ceiling)" % frac_of_streaming_ceiling
+        elif parked is not None and parked >= 0.4 and (busy or 0) < 0.6:
+            lim = "memory latency / synchronisation (waves parked on s_waitcnt or barriers %.2f of their time, vector ALU busy %.2f)" % (parked, busy or 0)
+        else:
+            lim = "mixed: hbm %.2f of the streaming ceiling, vector ALU busy %s" % (frac_of_streaming_ceiling or 0, "%.2f" % busy if busy is not None else "n/a")
+        return lim, ev
+    return "unclassified (no SQ counter record of this build under profiles/)", None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -221,28 +268,38 @@ def cv2_baseline(I0s, I1s, n_sample, algo):
 
 def cpu_baseline(I0s, I1s, n_sample, algo="TVL1"):
     """Oracle (CPU restatement, NOT OpenCV) timed on this box's host cores on a bounded sample of the same workload:
-    all granted cores, and one thread as the median over >= 3 pairs."""
+    all granted cores, and one thread as the median over >= 3 pairs.  What is timed is the
+    -O3 -march=native build of the oracle sources (`make -C oracle o3`, compiled on this machine by main() before the GPU is
+    touched) once it has reproduced the -O2 checker bit for bit on the sample's first pair; the returned flows -- the parity
+    reference -- always come from the checker build."""
     from oracle import oracle as O
     threads = O.effective_cpus()
     O.set_num_threads(threads)
     calc = O.tvl1_calc if algo == "TVL1" else O.deepflow_calc
-    calc(I0s[0], I1s[0])  # warm-up
-    flows = []
+    ref0 = calc(I0s[0], I1s[0])  # warm-up
+    fast, build = O.o3_calc(algo), "-O2 checker build (oracle/Makefile)"
+    if fast is not None:
+        if np.array_equal(fast(I0s[0], I1s[0]), ref0):
+            build = "-O3 -march=native -fopenmp -ffp-contract=off build of the same sources (bit-identical to the -O2 checker on the sample's first pair)"
+        else:
+            fast, build = None, "-O2 checker build (the -O3 -march=native build did NOT reproduce it bit for bit and was discarded)"
+    timed = fast if fast is not None else calc
     t0 = time.perf_counter()
     for i in range(n_sample):
-        flows.append(calc(I0s[i], I1s[i]))
+        timed(I0s[i], I1s[i])
     dt = time.perf_counter() - t0
+    flows = [ref0] + [calc(I0s[i], I1s[i]) for i in range(1, n_sample)]
     O.set_num_threads(1)
     one = []
     for i in range(min(3, len(I0s))):
         t1 = time.perf_counter()
-        calc(I0s[i], I1s[i])
+        timed(I0s[i], I1s[i])
         one.append(time.perf_counter() - t1)
     O.set_num_threads(threads)
     rec = {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
            "sample": f"{n_sample} of the benchmark's 512x512 pairs (seeds 0..{n_sample - 1}), 1 warm-up, "
                      f"oracle/{'tvl1' if algo == 'TVL1' else 'deepflow'}_oracle.c with {threads} OpenMP threads; restatement, not OpenCV",
-           "one_thread_pairs_per_s_median_of_3": 1.0 / float(np.median(one))}
+           "build": build, "one_thread_pairs_per_s_median_of_3": 1.0 / float(np.median(one))}
     return rec, flows
 
 
@@ -340,7 +397,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     fence()
     t0 = time.perf_counter()
     acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0,
-           "timed_iter_bytes": 0.0}
+           "timed_iter_bytes": 0.0, "sor_px": 0.0}
     for k in range(steps):
         st = step(warmup + k)
         acc["total_bytes"] += st["total_bytes"]; acc["inner"] += st["inner_iters_total"]; acc["outer"] += st["outer_iters_total"]
@@ -371,6 +428,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         for k in range(steps):
             st = step(warmup + steps + k)
             acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
+            acc["sor_px"] += st["iter_pair_steps"]
             for kk in ("ms_warp", "ms_median", "ms_misc", "ms_sched", "ms_device"):
                 acc["p_" + kk] = acc.get("p_" + kk, 0.0) + st[kk]
         drain()
@@ -391,11 +449,12 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         # ---- HBM traffic of the dominant kernel: live PMC passes (--pmc) or the stored passes of THIS build --------
         traffic = None
         traffic_source = None
+        ffac, ffac_src = fetch_factor(algo)
         if live_pmc and "fetch_kb" in live_pmc and "write_kb" in live_pmc:
-            traffic = (FETCH_FACTOR[algo] * live_pmc["fetch_kb"] + live_pmc["write_kb"]) * 1024.0
+            traffic = (ffac * live_pmc["fetch_kb"] + live_pmc["write_kb"]) * 1024.0
             traffic_source = {"kind": "live", "command": live_pmc.get("command"), "launches_profiled": live_pmc.get("launches"),
                               "fetch_size_kb_mean": live_pmc["fetch_kb"], "write_size_kb_mean": live_pmc["write_kb"],
-                              "fetch_size_factor": FETCH_FACTOR[algo]}
+                              "fetch_size_factor": ffac, "fetch_size_factor_source": ffac_src}
         else:
             rec, why = stored_record("hbm_traffic.json", kern)
             if rec:
@@ -405,21 +464,22 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                                   "launches_profiled": rec.get("launches_profiled"), "note": "PMC passes of this same kernel build, not of this run"}
             else:
                 traffic_source = {"kind": "none", "why": (live_pmc or {}).get("error") or why}
-        comp_bytes = 30.0 if algo == "TVL1" else None      # compulsory bytes per px-iteration of the fused two-iteration kernel
+        # compulsory bytes of the kernel that is launched: tvl1_iter 9 plane reads + 6 writes once per TWO iterations = 30 B per
+        # px-iteration; SOR 8 plane reads + 2 writes per launch of `sor_fuse` sweeps = 40 B per pixel and launch (tf_stats.iter_bytes
+        # charges 40 B per px-SWEEP, so the per-launch figure is iter_bytes / sweeps per launch)
+        comp_per_launch = units_per_launch * 30.0 if algo == "TVL1" else acc["sor_px"] * 40.0 / launches
         secs = avg_launch_ms / 1e3 if avg_launch_ms else None
         if traffic is not None and secs:
-            achieved, basis = traffic / 1e9 / secs, (f"measured HBM bytes per launch (PMC: {FETCH_FACTOR[algo]:g}*FETCH_SIZE + WRITE_SIZE"
-                                                     + (", gfx950 read correction for 16-B-per-lane loads" if FETCH_FACTOR[algo] == 2.0 else
-                                                        ", raw count: 8-B-per-lane loads, see FETCH_FACTOR in bench.py") + ") / mean launch time")
-        elif secs and comp_bytes:
-            achieved, basis = units_per_launch * comp_bytes / 1e9 / secs, "no PMC pass of this build: compulsory bytes of the fused kernel (30 B per px-iteration) / mean launch time"
+            achieved, basis = traffic / 1e9 / secs, (f"measured HBM bytes per launch (PMC: {ffac:g} x FETCH_SIZE + WRITE_SIZE; factor from {ffac_src}) / mean launch time")
         elif secs:
-            achieved, basis = units_per_launch * unit_bytes / 4 / 1e9 / secs, "no PMC pass of this build: 40 B per px-sweep / 4 sweeps fused per launch / mean launch time"
+            achieved, basis = comp_per_launch / 1e9 / secs, ("no PMC pass of this build: compulsory bytes of the launched kernel ("
+                                                             + ("30 B per px-iteration" if algo == "TVL1" else "40 B per pixel and launch") + ") / mean launch time")
         else:
             achieved, basis = None, "profiling off"
-        roof = {"bound": "hbm", "limiter": "valu-issue" if algo == "TVL1" else "lds-latency",
+        limiter, limiter_evidence = classify_limiter(kern, achieved / HBM_STREAM_GBS if achieved else None)
+        roof = {"bound": "hbm", "limiter": limiter, "limiter_evidence": limiter_evidence,
                 "kernel": kern + (" (tvl1_iter: two inner iterations per launch, full-width row strips)" if algo == "TVL1" else
-                                  " (red-black SOR, 4 sweeps per launch on 64x32 LDS tiles; 25 on levels that fit one block)"),
+                                  " (red-black SOR, 5 sweeps per launch on 128x64 regions held in registers; 25 on levels that fit one region)"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "frac_of_streaming_ceiling": achieved / HBM_STREAM_GBS if achieved else None,
                 "traffic": traffic, "traffic_source": traffic_source, "achieved_basis": basis,
@@ -427,6 +487,10 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                 ("px_iterations_per_launch" if algo == "TVL1" else "px_sweeps_per_launch"): units_per_launch,
                 "measured_on": f"{steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
         rate = units_per_launch / secs if secs else None
+        roof["algorithmic_bytes_per_launch"] = comp_per_launch
+        roof["algorithmic_GBps"] = comp_per_launch / 1e9 / secs if secs else None
+        roof["algorithmic_frac"] = comp_per_launch / 1e9 / secs / HBM_PEAK_GBS if secs else None
+        roof["traffic_over_algorithmic"] = traffic / comp_per_launch if traffic and comp_per_launch else None
         if algo == "TVL1":
             # algorithmic (compulsory) bytes of the kernel that is actually launched: 9 plane reads + 6 writes once per TWO iterations
             roof["algorithmic_GBps_30B"] = rate * 30.0 / 1e9 if rate else None
@@ -541,7 +605,7 @@ def main():
     ap.add_argument("--pmc", action="store_true", help="N=1 only: first run the FETCH_SIZE / WRITE_SIZE counter passes of this command as child "
                                                        "processes under rocprofv3 (adds ~1-2 min), so roofline.traffic is measured in this run")
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_live"))
-    ap.add_argument("--round-tag", default="r02")
+    ap.add_argument("--round-tag", default="r03")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps: no single-pair latency, no PCIe step (what the counter passes profile)")
     ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
@@ -567,6 +631,11 @@ def main():
     # ---- CPU-only preparation: nothing below this block may start a process ------------------------------------
     B, H, W = a.batch, a.size, a.size
     I0s, I1s = make_inputs(range(rank * B, (rank + 1) * B), H, W)          # rank r owns pairs [rB, (r+1)B): no data-path exchange
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not under_profiler():
+        from oracle import oracle as O
+        err = O.build_o3()                      # the timed baseline build is machine-specific: compile it here, before any GPU call
+        if err:
+            print(f"bench.py: `make -C oracle o3` failed, the -O2 checker will be timed instead: {err}", file=sys.stderr)
     want_df = a.algo == "TVL1" and world == 1 and not a.no_deepflow
     DB = min(a.deepflow_batch, B)
     live = {}
@@ -607,12 +676,11 @@ def main():
             for algo, lp in live.items():
                 if "fetch_kb" in lp and "write_kb" in lp:
                     rec[TVL1_KERNEL if algo == "TVL1" else DF_KERNEL] = {
-                        "bytes_per_launch": (FETCH_FACTOR[algo] * lp["fetch_kb"] + lp["write_kb"]) * 1024.0, "fetch_size_kb_mean": lp["fetch_kb"],
-                        "fetch_size_factor": FETCH_FACTOR[algo],
+                        "bytes_per_launch": (fetch_factor(algo)[0] * lp["fetch_kb"] + lp["write_kb"]) * 1024.0, "fetch_size_kb_mean": lp["fetch_kb"],
+                        "fetch_size_factor": fetch_factor(algo)[0], "fetch_size_factor_source": fetch_factor(algo)[1],
                         "write_size_kb_mean": lp["write_kb"], "launches_profiled": lp.get("launches"), "command": lp.get("command"),
                         "formula": "(fetch_size_factor*FETCH_SIZE + WRITE_SIZE)*1024 per launch, averaged over every launch of the kernel in a 1-step "
-                                   "single-lane run; factor 2 for 16-B-per-lane loads per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B), "
-                                   "1 for the 8-B-per-lane staging loads of k_df_sor_rt (see FETCH_FACTOR in bench.py); one --pmc pass per counter",
+                                   "single-lane run; the factor is calibrated per load width (tools/calibrate_fetch.sh); one --pmc pass per counter",
                         "source_fingerprint": out["kernel_source_fingerprint"], "round": a.round_tag}
             if rec:
                 os.makedirs(a.pmc_dir, exist_ok=True)

@@ -80,7 +80,8 @@ typedef struct tf_stats {
     double ms_h2d, ms_device, ms_d2h;
     /* dominant kernel (tvl1_iter): launches, summed duration (only when profiling is on) and bytes */
     unsigned long long iter_launches;
-    unsigned long long iter_pair_steps;    /* sum over launches of pairs that actually iterated */
+    unsigned long long iter_pair_steps;    /* DualTVL1: sum over launches of pairs that actually iterated; DeepFlow: pixels x pairs summed over
+                                              the SOR launches (a launch's compulsory traffic is 40 B per pixel) */
     double iter_ms;                        /* sum of tvl1_iter launch durations (tf_set_profile(h,1)) */
     double iter_bytes;                     /* algorithmic bytes of all executed pair-iterations (60 B/px) */
     double total_bytes;                    /* algorithmic bytes of the whole solve */

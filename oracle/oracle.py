@@ -309,3 +309,50 @@ def deepflow_calc(I0, I1, params=None, return_levels=False):
     if n <= 0:
         raise RuntimeError(f"dfo_deepflow_calc failed rc={n}")
     return (flow, n) if return_levels else flow
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the timed baseline build (-O3 -march=native, `make o3`): same sources, compiled on the machine that times them
+# ----------------------------------------------------------------------------------------------------------------------
+def build_o3():
+    """Compile the -O3 -march=native variants here and now (they are machine-specific and never travel).  Returns an error string or None."""
+    r = subprocess.run(["make", "-C", _HERE, "-s", "-B", "o3"], capture_output=True, text=True)
+    return None if r.returncode == 0 else (r.stderr or r.stdout)[-400:]
+
+
+def o3_calc(algo):
+    """calc(I0, I1) -> flow through the -O3 build, or None when it has not been built on this machine."""
+    path = os.path.join(_HERE, "libtvl1_oracle_o3.so" if algo == "TVL1" else "libdeepflow_oracle_o3.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    if algo == "TVL1":
+        L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_tvl1_calc.argtypes = [C.POINTER(OrcParams), u8p, u8p, C.c_int, C.c_int, fp, C.c_void_p]
+        L.orc_tvl1_calc.restype = C.c_int
+        p = OrcParams()
+        L.orc_default_params(C.byref(p))
+
+        def calc(I0, I1):           # thread count: set_num_threads() (one OpenMP runtime serves every oracle library of the process)
+            h, w = I0.shape
+            flow = np.empty((h, w, 2), np.float32)
+            if L.orc_tvl1_calc(C.byref(p), np.ascontiguousarray(I0), np.ascontiguousarray(I1), h, w, flow.reshape(-1), None) <= 0:
+                raise RuntimeError("orc_tvl1_calc (o3) failed")
+            return flow
+        return calc
+    L.dfo_default_params.argtypes = [C.POINTER(DfoParams)]
+    L.dfo_deepflow_calc.argtypes = [C.POINTER(DfoParams), u8p, u8p, C.c_int, C.c_int, fp]
+    L.dfo_deepflow_calc.restype = C.c_int
+    p = DfoParams()
+    L.dfo_default_params(C.byref(p))
+
+    def calc(I0, I1):
+        h, w = I0.shape
+        flow = np.empty((h, w, 2), np.float32)
+        if L.dfo_deepflow_calc(C.byref(p), np.ascontiguousarray(I0), np.ascontiguousarray(I1), h, w, flow.reshape(-1)) <= 0:
+            raise RuntimeError("dfo_deepflow_calc (o3) failed")
+        return flow
+    return calc

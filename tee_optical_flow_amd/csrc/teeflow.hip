@@ -81,6 +81,7 @@ struct tf_handle {
     // per-call accumulators
     unsigned long long iter_launches = 0;
     double df_sor_bytes = 0;     // DeepFlow: algorithmic bytes of the SOR launches of the current call (40 B per pixel-sweep)
+    double df_sor_px = 0;        // DeepFlow: pixels x pairs summed over the SOR launches (a launch's compulsory traffic is 40 B per pixel: 8 planes in, 2 out)
     // ---- DeepFlow (algo == TF_ALGO_DEEPFLOW) ----
     tf_deepflow_params DP = {};
     int dnlev = 0, dH = 0, dW = 0, dcap = 0;
@@ -728,6 +729,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             ++h->iter_launches;
             const int n = launch_sor_rt(h, d, g, B, c.omega, left, fuse > 8 ? 8 : fuse, s);
             h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;
+            h->df_sor_px += (double)g.w * g.h * B;
             if (pe) (void)hipEventRecord(pe->b, s);
             std::swap(d.du, d.du2); std::swap(d.dv, d.dv2);
             left -= n;
@@ -809,7 +811,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     const size_t npx = (size_t)H * W;
     h->last_iters.assign(deep ? 0 : (size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
     h->last_pairs = n_pairs; h->last_nlev = deep ? h->dnlev : h->nlev; h->last_warps = deep ? 0 : h->P.warps;
-    h->iter_launches = 0; h->prof_used = 0; h->df_sor_bytes = 0;
+    h->iter_launches = 0; h->prof_used = 0; h->df_sor_bytes = 0; h->df_sor_px = 0;
     float ms_h2d = 0, ms_dev = 0, ms_d2h = 0;
     // Host destinations that are pinned (tf_host_alloc, hipHostMalloc, hipHostRegister) take the overlapped path: each
     // sub-batch is solved into one half of a double staging buffer and copied out on a second stream while the next one
@@ -886,11 +888,11 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         st->n_pairs = n_pairs; st->nscales_used = deep ? h->dnlev : h->nlev; st->warps = deep ? 0 : h->P.warps;
         st->ms_h2d = ms_h2d; st->ms_device = ms_dev; st->ms_d2h = ms_d2h;
         st->iter_launches = h->iter_launches;
-        if (deep) { st->total_bytes = df_account_bytes(h) * n_pairs; st->iter_bytes = h->df_sor_bytes; }
+        if (deep) { st->total_bytes = df_account_bytes(h) * n_pairs; st->iter_bytes = h->df_sor_bytes; st->iter_pair_steps = (unsigned long long)h->df_sor_px; }
         for (int b = 0; !deep && b < n_pairs; ++b)
             account_bytes(h, h->last_iters.data() + (size_t)b * h->nlev * h->P.warps * 2, &st->iter_bytes, &st->total_bytes,
                           &st->inner_iters_total, &st->outer_iters_total);
-        st->iter_pair_steps = st->inner_iters_total;
+        if (!deep) st->iter_pair_steps = st->inner_iters_total;     // DeepFlow: pixels x pairs summed over the SOR launches (set above)
         double ims = 0;
         h->warp_ms = h->median_ms = 0;
         for (size_t i = 0; i < h->prof_used; ++i) {

@@ -52,7 +52,11 @@ def test_profiler_detection_and_input_cache(tmp_path, monkeypatch):
 
 def test_fetch_factors_and_committed_records_are_well_formed():
     import bench
-    assert bench.FETCH_FACTOR == {"TVL1": 2.0, "deepflow": 1.0}
+    for algo in ("TVL1", "deepflow"):                            # calibrated on the GPU (profiles/r03_fetch_calibration.json): 2.0 at every width
+        f, src = bench.fetch_factor(algo)
+        assert f == 2.0 and "fetch_calibration" in src
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r03_fetch_calibration.json")))["kernels"]
+    assert set(cal) >= {"4", "8", "16", "8_tile_rows"} and all(abs(k["fetch_factor"] - 2.0) < 0.01 and abs(k["write_factor"] - 1.0) < 0.01 for k in cal.values())
     for name in ("hbm_traffic.json", "isa_stats.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
@@ -81,3 +85,24 @@ def test_spawn_ranks_sets_the_rendezvous_and_reports_failures(tmp_path):
     assert len({e["MASTER_PORT"] for e in envs}) == 1 and {e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in envs} == {"0"}
     rc, out = bench.spawn_ranks(2, [str(tmp_path), "7"], script=str(child), timeout=60)
     assert rc == 7 and json.loads(out)["rank"] == 0
+
+
+def test_limiter_is_derived_from_counter_records(tmp_path, monkeypatch):
+    """roofline.limiter comes from the stored SQ counters of the build, not from a literal."""
+    import bench
+    fp = "f" * 16
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_fingerprint", lambda: fp)
+    (tmp_path / "profiles").mkdir()
+    assert bench.classify_limiter("k_x", 0.5)[0].startswith("unclassified")
+    rec = {"k_x": {"source_fingerprint": fp, "derived": {"valu_pipe_busy_per_simd_all_launches": 0.91, "wave_time_share_parked_waitcnt_or_barrier": 0.2,
+                                                          "wave_time_share_issue_stalled": 0.3, "mean_waves_per_simd_resident": 3.9}},
+           "k_y": {"source_fingerprint": fp, "derived": {"valu_pipe_busy_per_simd_all_launches": 0.35, "wave_time_share_parked_waitcnt_or_barrier": 0.55,
+                                                          "wave_time_share_issue_stalled": 0.1, "mean_waves_per_simd_resident": 3.0}},
+           "k_z": {"source_fingerprint": "0" * 16, "derived": {"valu_pipe_busy_per_simd_all_launches": 0.99}}}
+    (tmp_path / "profiles" / "r09_sq_counters.json").write_text(json.dumps(rec))
+    lim, ev = bench.classify_limiter("k_x", 0.4)
+    assert lim.startswith("valu") and ev["valu_pipe_busy_per_simd"] == 0.91 and ev["source"] == "profiles/r09_sq_counters.json"
+    assert bench.classify_limiter("k_y", 0.85)[0].startswith("hbm")
+    assert bench.classify_limiter("k_y", 0.45)[0].startswith("memory latency")
+    assert bench.classify_limiter("k_z", 0.45)[0].startswith("unclassified")          # another build's counters are not used

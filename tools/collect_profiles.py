@@ -4,7 +4,7 @@
   <tag>_bench_pmc.json                                      the line of `bench.py --pmc` (roofline.traffic measured in that run)
   hbm_traffic.json                                          FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels, tagged with the kernel source fingerprint
   <tag>_sq_counters.json                                    SQ / GRBM counters of k_iter2_rows and k_df_sor_rt: totals, per-launch means, derived shares
-usage: python tools/collect_profiles.py r02 [destination directory, default profiles/]"""
+usage: python tools/collect_profiles.py r03 [destination directory, default profiles/]"""
 import collections
 import csv
 import glob
@@ -47,7 +47,9 @@ def sq_summary(tag, algo, kernel):
         for k, x in row.items():
             if not k.startswith("_"):
                 tot[k] += x; cnt[k] += 1
-    out = {"kernel": kernel, "dispatches": n, "command": f"tools/pmc_sq.sh {tag} {algo}  (rocprofv3 --pmc <<=5 counters per pass> --kernel-include-regex ... -- "
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_fingerprint
+    out = {"kernel": kernel, "source_fingerprint": kernel_source_fingerprint(), "dispatches": n, "command": f"tools/pmc_sq.sh {tag} {algo}  (rocprofv3 --pmc <<=5 counters per pass> --kernel-include-regex ... -- "
                                                            "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --lanes 1 --no-deepflow" + (" --algo deepflow --batch 64)" if algo == "deepflow" else ")"),
            "units": "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
            "totals": {k: tot[k] for k in sorted(tot)}, "per_dispatch_mean": {k: tot[k] / cnt[k] for k in sorted(tot)}}
@@ -79,7 +81,7 @@ def sq_summary(tag, algo, kernel):
 
 def main():
     global DST
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     if len(sys.argv) > 2:                       # on the GPU box: condense into a small directory under gpurun_out/ (profiles/ does not travel back)
         DST = sys.argv[2]
         os.makedirs(DST, exist_ok=True)

@@ -4,7 +4,7 @@
 # Raw CSVs land under gpurun_out/pmc_sq_<tag>/; tools/collect_pmc.py condenses them into profiles/.
 # usage: bash tools/pmc_sq.sh <round-tag> [TVL1|deepflow]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ALGO=${2:-TVL1}
 KREGEX=${KREGEX:-"k_iter2_rows|k_df_sor_rt"}     # other kernels: KREGEX="k_median2|k_warp" bash tools/pmc_sq.sh r02x
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_$ALGO

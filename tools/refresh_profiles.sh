@@ -6,9 +6,9 @@
 #   3. per-launch profile of the lock-step driver (tools/launch_profile.py) and the arithmetic ablation probe
 #   4. SQ / GRBM counter passes over the dominant kernels (tools/pmc_sq.sh)
 # Outputs under gpurun_out/prof_<tag>/ ; tools/collect_profiles.py <tag> condenses them into profiles/.
-# usage: bash tools/refresh_profiles.sh <round-tag, e.g. r02>
+# usage: bash tools/refresh_profiles.sh <round-tag, e.g. r03>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
