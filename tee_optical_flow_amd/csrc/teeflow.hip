@@ -119,7 +119,8 @@ struct tf_handle {
     float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
     int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
-    int sor_rt_shape = 1;        // k_df_sor_rt: 0 = 8 bands x 8 rows (512 threads), 1 = 16 bands x 4 rows (1024 threads)
+    int sor_rt_shape = 3;        // k_df_sor_rt: 0 = 8 bands x 8 rows (512 threads), 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
+                                 // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
     int df_fuse_ds = 1;          // DeepFlow: data term + smoothness contributions in one kernel (0: k_df_data then k_df_smooth)
     int sor_fuse = 5;            // DeepFlow: complete red-black SOR sweeps per launch of k_df_sor_rt (0 = one colour per launch, in place).
                                  // 64 pairs @512^2: 466 / 534 / 562 / 548 / 567 pairs/s for 3 / 4 / 5 / 6 / 7; 5 divides the 25 sweeps evenly
@@ -687,14 +688,33 @@ void launch_sor_rt_t(const DfBufs& d, const Geom& g, int B, float omega, int swe
     const int ny = g.h <= RH ? 1 : 1 + (g.h - RH + (RH - 2 * hl) - 1) / (RH - 2 * hl);
     hipLaunchKernelGGL((k_df_sor_rt<R, NB>), dim3(nx, ny, B), dim3(64 * NB), 0, s, d, g, omega, sweeps, hl);
 }
-// returns the number of sweeps it ran (all of `left` when the level fits one region)
+// returns the number of sweeps it ran (all of `left` when the level fits one region).
+// Region shapes: 128 x 64 held by 16 bands x 4 rows (1024 threads, one block per CU) is the throughput shape -- least halo.  When it
+// would leave most of the chip idle (a single pair, or the small levels of a batch: fewer blocks than CUs) the same 4-row bands are
+// stacked only 8 high: 128 x 32 regions, 512 threads, two blocks per CU, ~2.5x the blocks and half the sweep time per block -- as
+// long as they all fit one round of resident blocks.  (64 pairs @512^2 are unaffected; single pair 27.3 -> see DESIGN.md.)
 int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float omega, int left, int fuse, hipStream_t s)
 {
-    const int RH = 64;
-    const bool whole = g.w <= 128 && g.h <= RH;
-    const int n = whole ? left : (left < fuse ? left : fuse);
+    auto tiles = [&](int RH, int hl) {
+        const int nx = g.w <= 128 ? 1 : 1 + (g.w - 128 + (128 - 2 * hl) - 1) / (128 - 2 * hl);
+        const int ny = g.h <= RH ? 1 : 1 + (g.h - RH + (RH - 2 * hl) - 1) / (RH - 2 * hl);
+        return nx * ny;
+    };
+    int shape = h->sor_rt_shape;
+    const bool whole64 = g.w <= 128 && g.h <= 64, whole32 = g.w <= 128 && g.h <= 32;
+    if (shape == 3) {
+        shape = 1;
+        const int n5 = left < fuse ? left : fuse;
+        if (whole32) shape = 2;                                            // fits 8 bands: half the waves, same sweeps
+        else if (!whole64 && 32 - 4 * n5 >= 8 && tiles(64, 2 * n5) * B < h->num_cus && tiles(32, 2 * n5) * B <= 2 * h->num_cus) shape = 2;
+    }
+    const bool whole = shape == 2 ? whole32 : whole64;
+    int n = whole ? left : (left < fuse ? left : fuse);
+    if (!whole && shape == 2 && 32 - 4 * n < 4) n = 6;                     // 128 x 32 regions: at most 6 sweeps per launch (core of 8 rows)
+    if (n > left) n = left;
     const int hl = whole ? 0 : 2 * n;
-    if (h->sor_rt_shape == 0) launch_sor_rt_t<8, 8>(d, g, B, omega, n, hl, s);
+    if (shape == 0) launch_sor_rt_t<8, 8>(d, g, B, omega, n, hl, s);
+    else if (shape == 2) launch_sor_rt_t<4, 8>(d, g, B, omega, n, hl, s);
     else launch_sor_rt_t<4, 16>(d, g, B, omega, n, hl, s);
     return n;
 }

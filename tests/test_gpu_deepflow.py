@@ -33,12 +33,14 @@ def test_blur_bit_exact(deep, oracle, shape):
     assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("fuse,shape_knob", [(0, 0), (1, 0), (2, 1), (3, 0), (3, 1), (4, 1), (5, 0), (5, 1), (6, 1), (7, 0), (8, 1)])
+@pytest.mark.parametrize("fuse,shape_knob", [(0, 0), (1, 0), (2, 1), (3, 0), (3, 1), (4, 1), (5, 0), (5, 1), (6, 1), (7, 0), (8, 1),
+                                             (1, 2), (3, 2), (5, 2), (6, 2), (8, 2), (5, 3), (3, 3)])
 @pytest.mark.parametrize("shape,amp", [((64, 64), 1.0), ((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((70, 200), 2.0), ((96, 96), 3.0), ((150, 301), 2.0), ((333, 141), 1.0)])
 def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_knob):
     """One cv::VariationalRefinement::calcUV (warp, 8 derivative planes, 5 x [data term, smoothness, 25 red-black SOR sweeps]) in
     every SOR form: one colour per launch (fuse 0), n sweeps per launch of the register-tile kernel on 128 x 64 regions held by
-    8 bands x 8 rows (shape 0) or 16 bands x 4 rows (shape 1); a level that fits one region runs all 25 sweeps in one launch."""
+    8 bands x 8 rows (shape 0) or 16 bands x 4 rows (shape 1), on 128 x 32 regions held by 8 bands x 4 rows (shape 2), or the
+    launcher's own choice between 1 and 2 (shape 3, the default); a level that fits one region runs all 25 sweeps in one launch."""
     from scipy import ndimage
     from tee_optical_flow_amd import _lib
     L = _lib.load()
@@ -56,7 +58,7 @@ def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_
         _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
     finally:
         deep.set_tuning("sor_fuse", 5)
-        deep.set_tuning("sor_rt_shape", 1)
+        deep.set_tuning("sor_rt_shape", 3)
     assert np.array_equal(gu, ru), f"u: {np.sum(gu != ru)} differ, max {np.abs(gu - ru).max()}"
     assert np.array_equal(gv, rv)
 

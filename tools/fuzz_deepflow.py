@@ -25,7 +25,7 @@ def main():
         if rng.random() < 0.25:
             I1s[0] = I0s[0]
         eng = T.DenseFlow(algo="deepflow", max_batch=int(rng.choice([B, max(1, B // 2)])))
-        shape = int(rng.choice([0, 1]))                   # register-tile SOR: 8 bands x 8 rows / 16 bands x 4 rows
+        shape = int(rng.choice([0, 1, 2, 3, 3]))          # register-tile SOR: 8 x 8 / 16 x 4 / 8 x 4 bands / chosen per launch
         fuse = int(rng.choice([0, 1, 2, 3, 4, 5, 5, 6, 7, 8]))   # sweeps per launch (0: one colour per launch)
         eng.set_tuning("sor_rt_shape", shape)
         eng.set_tuning("sor_fuse", fuse)
