@@ -121,7 +121,8 @@ struct tf_handle {
     int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
     int sor_rt_shape = 3;        // k_df_sor_rt: 0 = 8 bands x 8 rows (512 threads), 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
                                  // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
-    int df_fuse_ds = 1;          // DeepFlow: data term + smoothness contributions in one kernel (0: k_df_data then k_df_smooth)
+    int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (2: four pixels per thread, 16-byte loads; 1: one pixel per
+                                 // thread; 0: k_df_data then k_df_smooth)
     int sor_fuse = 5;            // DeepFlow: complete red-black SOR sweeps per launch of k_df_sor_rt (0 = one colour per launch, in place).
                                  // 64 pairs @512^2: 466 / 534 / 562 / 548 / 567 pairs/s for 3 / 4 / 5 / 6 / 7; 5 divides the 25 sweeps evenly
     int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
@@ -731,7 +732,8 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
     hipLaunchKernelGGL(k_df_grad2, gr, bl, 0, s, d, g);
     const int fuse = h->sor_fuse < 0 ? 0 : h->sor_fuse;
     for (int fp = 0; fp < h->DP.fixed_point_iterations; ++fp) {
-        if (h->df_fuse_ds) hipLaunchKernelGGL(k_df_data_smooth, gr, bl, 0, s, d, cur, g, c);
+        if (h->df_fuse_ds == 2) hipLaunchKernelGGL(k_df_data_smooth4, dim3((g.w + 255) / 256, (g.h + 3) / 4, B), bl, 0, s, d, cur, g, c);
+        else if (h->df_fuse_ds) hipLaunchKernelGGL(k_df_data_smooth, gr, bl, 0, s, d, cur, g, c);
         else {
             hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
             hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
@@ -1233,7 +1235,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
-    else if (n == "df_fuse_ds") h->df_fuse_ds = value ? 1 : 0;
+    else if (n == "df_fuse_ds") h->df_fuse_ds = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;

@@ -63,6 +63,30 @@ def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_
     assert np.array_equal(gv, rv)
 
 
+@pytest.mark.parametrize("ds", [0, 1, 2])
+@pytest.mark.parametrize("shape,amp", [((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((150, 301), 2.0), ((333, 141), 1.0), ((65, 258), 3.0)])
+def test_data_and_smoothness_term_forms_bit_exact(deep, oracle, shape, amp, ds):
+    """The linear system of a fixed-point iteration in its three kernel forms: k_df_data + k_df_smooth (0), both in one pass with one
+    pixel per thread (1), four pixels per thread with 16-byte loads (2, the default) -- through a full calcUV against the oracle."""
+    from scipy import ndimage
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(5)
+    I0 = ndimage.gaussian_filter(rng.uniform(0, 255, (h, w)), 1.5).astype(np.float32)
+    I1 = ndimage.shift(I0, (-0.4, 0.9), order=1, mode="nearest").astype(np.float32)
+    u = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
+    v = rng.uniform(-amp, amp, (h, w)).astype(np.float32)
+    ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
+    gu, gv = u.copy(), v.copy()
+    deep.set_tuning("df_fuse_ds", ds)
+    try:
+        _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    finally:
+        deep.set_tuning("df_fuse_ds", 2)
+    assert np.array_equal(gu, ru) and np.array_equal(gv, rv)
+
+
 @pytest.mark.parametrize("seed,H,W", [(0, 96, 96), (1, 120, 160), (2, 64, 200), (3, 100, 75), (4, 55, 123), (5, 75, 139)])     # odd widths: the last lane's second column is row padding
 def test_deepflow_pair_matches_oracle(deep, oracle, seed, H, W):
     from tee_optical_flow_amd.synth import speckle_pair

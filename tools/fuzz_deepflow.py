@@ -29,6 +29,7 @@ def main():
         fuse = int(rng.choice([0, 1, 2, 3, 4, 5, 5, 6, 7, 8]))   # sweeps per launch (0: one colour per launch)
         eng.set_tuning("sor_rt_shape", shape)
         eng.set_tuning("sor_fuse", fuse)
+        eng.set_tuning("df_fuse_ds", int(rng.choice([0, 1, 2, 2])))
         flows = eng.calc_pairs(I0s, I1s)
         ok = True
         for b in sorted(set([0, B - 1])):
