@@ -1,7 +1,12 @@
 import os
 import sys
 
-import pytest
+# The CPU oracles are OpenMP code.  On a host whose cores are shared (CI, a GPU box that grants 16 of 256 hardware threads) a spinning
+# OpenMP team turns a 1-second test into minutes: make idle threads sleep, before anything loads libgomp.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
