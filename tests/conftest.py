@@ -1,10 +1,11 @@
 import os
 import sys
 
-# The CPU oracles are OpenMP code.  On a host whose cores are shared (CI, a GPU box that grants 16 of 256 hardware threads) a spinning
-# OpenMP team turns a 1-second test into minutes: make idle threads sleep, before anything loads libgomp.
-os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-os.environ.setdefault("GOMP_SPINCOUNT", "0")
+# The CPU oracles are OpenMP code with thousands of short parallel regions.  libgomp's default lets an idle thread spin for ~300k
+# iterations: on a host whose cores are shared (CI, a GPU box that grants 16 of 256 hardware threads) that turned a 1-second oracle test
+# into minutes; sleeping at once (OMP_WAIT_POLICY=PASSIVE) costs a futex round trip per region instead (the suite: 25 s -> 144 s).  A short
+# spin, set before anything loads libgomp, is fast when the cores are free and harmless when they are not.
+os.environ.setdefault("GOMP_SPINCOUNT", "20000")
 
 import pytest  # noqa: E402
 
