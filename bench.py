@@ -8,7 +8,7 @@ for N > 1 -- the (u,v) fields are all-gathered over RCCL (the one exchange step 
 with the next step's compute.  value = pairs all ranks solved / max-over-ranks wall time.
 
 The default N=1 run then measures BASELINE configs[3] (OF_algo='deepflow', the algorithm the reference's own CLI
-hard-codes, calculate_optical_flow.py:735-739) the same way on 64 pairs and reports it under "deepflow" in the
+hard-codes, calculate_optical_flow.py:735-739) the same way on 128 pairs and reports it under "deepflow" in the
 same JSON line.
 
 Everything that is not GPU work (synthetic inputs, the optional `--pmc` counter passes, which run this script as a
@@ -218,7 +218,7 @@ def pmc_child_passes(algo, out_dir, tag="live"):
         d = os.path.join(out_dir, f"pmc_{tag}_{algo}_{ctr}")
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-include-regex", kern, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile",
-               "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo] + (["--batch", "64"] if algo != "TVL1" else [])
+               "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo] + (["--batch", "128"] if algo != "TVL1" else [])
         env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
         r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         if r.returncode != 0:
@@ -600,7 +600,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket tvl1_iter launches with HIP events")
     ap.add_argument("--algo", default="TVL1", choices=["TVL1", "deepflow"], help="BASELINE configs[1..2] (TVL1, default) or configs[3] (deepflow) as the main leg")
     ap.add_argument("--no-deepflow", action="store_true", help="skip the DeepFlow leg the default N=1 TVL1 run appends")
-    ap.add_argument("--deepflow-batch", type=int, default=64)
+    ap.add_argument("--deepflow-batch", type=int, default=128, help="pairs per step of the DeepFlow leg (64 pairs: 577, 128: 601-607, 256: 608 pairs/s on one MI355X)")
     ap.add_argument("--deepflow-steps", type=int, default=2)
     ap.add_argument("--pmc", action="store_true", help="N=1 only: first run the FETCH_SIZE / WRITE_SIZE counter passes of this command as child "
                                                        "processes under rocprofv3 (adds ~1-2 min), so roofline.traffic is measured in this run")

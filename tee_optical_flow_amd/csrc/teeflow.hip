@@ -119,6 +119,7 @@ struct tf_handle {
     float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
     int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
+    int sor_plain_div = 0;       // tests: k_df_sor_rt takes its plain-IEEE-division path (what a block with out-of-range diagonals does)
     int sor_rt_shape = 3;        // k_df_sor_rt: 0 = 8 bands x 8 rows (512 threads), 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
                                  // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
     int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (2: four pixels per thread, 16-byte loads; 1: one pixel per
@@ -682,12 +683,12 @@ void df_gauss3(float sigma, float* k0, float* k1)
 // register-tile SOR (teeflow_sor_rt.hip.h): `sweeps` sweeps per launch on 128 x (R*NB) regions with a halo of hl = 2 * sweeps
 // (hl = 0: the region holds the whole level)
 template <int R, int NB>
-void launch_sor_rt_t(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, int hl, hipStream_t s)
+void launch_sor_rt_t(const DfBufs& d, const Geom& g, int B, float omega, int sweeps, int hl, hipStream_t s, int plain_div)
 {
     constexpr int RW = 128, RH = R * NB;
     const int nx = g.w <= RW ? 1 : 1 + (g.w - RW + (RW - 2 * hl) - 1) / (RW - 2 * hl);
     const int ny = g.h <= RH ? 1 : 1 + (g.h - RH + (RH - 2 * hl) - 1) / (RH - 2 * hl);
-    hipLaunchKernelGGL((k_df_sor_rt<R, NB>), dim3(nx, ny, B), dim3(64 * NB), 0, s, d, g, omega, sweeps, hl);
+    hipLaunchKernelGGL((k_df_sor_rt<R, NB>), dim3(nx, ny, B), dim3(64 * NB), 0, s, d, g, omega, sweeps, hl, plain_div);
 }
 // returns the number of sweeps it ran (all of `left` when the level fits one region).
 // Region shapes: 128 x 64 held by 16 bands x 4 rows (1024 threads, one block per CU) is the throughput shape -- least halo.  When it
@@ -714,9 +715,9 @@ int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float ome
     if (!whole && shape == 2 && 32 - 4 * n < 4) n = 6;                     // 128 x 32 regions: at most 6 sweeps per launch (core of 8 rows)
     if (n > left) n = left;
     const int hl = whole ? 0 : 2 * n;
-    if (shape == 0) launch_sor_rt_t<8, 8>(d, g, B, omega, n, hl, s);
-    else if (shape == 2) launch_sor_rt_t<4, 8>(d, g, B, omega, n, hl, s);
-    else launch_sor_rt_t<4, 16>(d, g, B, omega, n, hl, s);
+    if (shape == 0) launch_sor_rt_t<8, 8>(d, g, B, omega, n, hl, s, h->sor_plain_div);
+    else if (shape == 2) launch_sor_rt_t<4, 8>(d, g, B, omega, n, hl, s, h->sor_plain_div);
+    else launch_sor_rt_t<4, 16>(d, g, B, omega, n, hl, s, h->sor_plain_div);
     return n;
 }
 
@@ -975,7 +976,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->tile_max_w = h->tile_max_w;
+        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->sor_plain_div = h->sor_plain_div; t->tile_max_w = h->tile_max_w;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1230,6 +1231,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "tile_max_w") h->tile_max_w = value;
     else if (n == "sor_rt") h->sor_rt = value ? 1 : 0;
     else if (n == "sor_rt_shape") h->sor_rt_shape = value;
+    else if (n == "sor_plain_div") h->sor_plain_div = value ? 1 : 0;
     else if (n == "tile2") h->tile2 = value;
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;

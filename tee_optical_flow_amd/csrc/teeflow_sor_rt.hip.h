@@ -218,7 +218,7 @@ __device__ __forceinline__ void sor_rt_sweeps(SorRtState<R, NB>& t, float2 (*exT
 
 // grid (tiles x, tiles y, pairs), 64 * NB threads.  R even (row parity of a thread's rows must not depend on the band).
 template <int R, int NB>
-__global__ __launch_bounds__(64 * NB) void k_df_sor_rt(DfBufs d, Geom g, float omega, int nsw, int hl)
+__global__ __launch_bounds__(64 * NB) void k_df_sor_rt(DfBufs d, Geom g, float omega, int nsw, int hl, int plain_div)
 {
     static_assert(R % 2 == 0, "rows per band must be even");
     constexpr int RW = 128, RH = R * NB;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64 * NB) void k_df_sor_rt(DfBufs d, Geom g, float o
     const size_t po = (size_t)b * g.splane;
     SorRtState<R, NB> t;
     rt_band_issue_loads(t, d, po, gy0, gx, W, H, pitch, wv > 0);
-    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, wv > 0);
+    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, wv > 0) | plain_div;      // plain_div: tests force the plain-division path
     exT[wv][0][ln] = make_float2(t.du[0][0], t.dv[0][0]); exT[wv][1][ln] = make_float2(t.du[0][1], t.dv[0][1]);
     exB[wv + 1][0][ln] = make_float2(t.du[R - 1][0], t.dv[R - 1][0]); exB[wv + 1][1][ln] = make_float2(t.du[R - 1][1], t.dv[R - 1][1]);
     if (wv == 0) {

@@ -63,6 +63,31 @@ def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_
     assert np.array_equal(gv, rv)
 
 
+@pytest.mark.parametrize("shape_knob", [0, 1, 2])
+def test_sor_plain_division_path_bit_exact(deep, oracle, shape_knob):
+    """A block whose diagonals leave the range the pre-scaled division is exact for takes the plain IEEE division; real data never
+    gets there, so the path is forced (sor_plain_div) -- both divisions are correctly rounded, the results must not move."""
+    from scipy import ndimage
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = 150, 301
+    rng = np.random.default_rng(13)
+    I0 = ndimage.gaussian_filter(rng.uniform(0, 255, (h, w)), 1.5).astype(np.float32)
+    I1 = ndimage.shift(I0, (0.3, -0.8), order=1, mode="nearest").astype(np.float32)
+    u = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    v = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
+    gu, gv = u.copy(), v.copy()
+    deep.set_tuning("sor_plain_div", 1)
+    deep.set_tuning("sor_rt_shape", shape_knob)
+    try:
+        _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    finally:
+        deep.set_tuning("sor_plain_div", 0)
+        deep.set_tuning("sor_rt_shape", 3)
+    assert np.array_equal(gu, ru) and np.array_equal(gv, rv)
+
+
 @pytest.mark.parametrize("ds", [0, 1, 2])
 @pytest.mark.parametrize("shape,amp", [((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((150, 301), 2.0), ((333, 141), 1.0), ((65, 258), 3.0)])
 def test_data_and_smoothness_term_forms_bit_exact(deep, oracle, shape, amp, ds):
@@ -135,3 +160,19 @@ def test_deepflow_identical_frames_zero_and_errors(deep):
     m = __import__("tee_optical_flow_amd.pipeline", fromlist=["make_flow_model"]).make_flow_model("deepflow")
     assert m.algo == "deepflow"
     m.close()
+
+
+def test_deepflow_sector_masked_frames(deep, oracle):
+    """Echo frames are exactly black outside the ultrasound sector: next to such flat regions du, dv decay geometrically, through
+    1e-30 into the denormal range -- the case the SOR kernel's pre-scaled division (x 2^64, refined reciprocal, v_div_fixup) exists for."""
+    from tee_optical_flow_amd.synth import speckle_sequence
+    H, W = 200, 264
+    yy, xx = np.mgrid[0:H, 0:W]
+    ang = np.arctan2(xx - W / 2, yy + H * 0.05)
+    sector = (np.abs(ang) < 0.7) & (np.hypot(xx - W / 2, yy + H * 0.05) < H * 0.98)
+    fr = np.where(sector[None], speckle_sequence(77, 3, H, W), 0).astype(np.uint8)
+    flows = deep.calc_batch(fr)
+    for i in range(2):
+        ref = oracle.deepflow_calc(fr[i], fr[i + 1])
+        assert np.array_equal(np.asarray(flows[i]).view(np.uint32), ref.view(np.uint32)) or np.array_equal(flows[i], ref), f"pair {i}"
+        assert np.isfinite(ref).all() and (np.abs(ref[~sector]) < 1e-3).mean() > 0.5      # the flat region really is (nearly) still

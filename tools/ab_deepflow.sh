@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/ab
 for cfg in "$@"; do
-  timeout -k 10 300 python3 bench.py --algo deepflow --batch ${DF_BATCH:-64} --steps 3 --no-cpu-baseline --tuning "$cfg" > gpurun_out/ab/df.json 2> gpurun_out/ab/df.err && python3 - "$cfg" <<'PY' || { echo "FAILED $cfg"; tail -3 gpurun_out/ab/df.err; }
+  timeout -k 10 300 python3 bench.py --algo deepflow --batch ${DF_BATCH:-128} --steps 3 --no-cpu-baseline --tuning "$cfg" > gpurun_out/ab/df.json 2> gpurun_out/ab/df.err && python3 - "$cfg" <<'PY' || { echo "FAILED $cfg"; tail -3 gpurun_out/ab/df.err; }
 import json, sys
 d = json.load(open("gpurun_out/ab/df.json")); r = d["roofline"]
 print("%-36s pairs/s %6.1f ms/step %7.2f | SOR launches/step %5.0f avg ms %.4f px-sweeps/s %.1fG latency %.1f ms" % (

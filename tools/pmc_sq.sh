@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 cd /tmp
 [ -f $OUT/../counters_list.txt ] || rocprofv3 -L > $OUT/../counters_list.txt 2>&1
 EXTRA=""
-[ "$ALGO" = "deepflow" ] && EXTRA="--batch 64"
+[ "$ALGO" = "deepflow" ] && EXTRA="--batch 128"
 [ -n "${TUNING:-}" ] && EXTRA="$EXTRA --tuning $TUNING"          # engine knobs for an experiment: TUNING=sor_fuse=7 bash tools/pmc_sq.sh x deepflow
 pass() {
   local name=$1; shift
