@@ -163,8 +163,9 @@ def test_deepflow_identical_frames_zero_and_errors(deep):
 
 
 def test_deepflow_sector_masked_frames(deep, oracle):
-    """Echo frames are exactly black outside the ultrasound sector: next to such flat regions du, dv decay geometrically, through
-    1e-30 into the denormal range -- the case the SOR kernel's pre-scaled division (x 2^64, refined reciprocal, v_div_fixup) exists for."""
+    """Echo frames are exactly black outside the ultrasound sector: there the data term vanishes (Ix = Iy = Iz = 0: a11 = a22 = zeta^2 + the
+    smoothness weights, b = the smoothness contributions alone) and the flow is filled in from the sector's edge -- diagonals and right-hand
+    sides orders of magnitude away from the textured case, through the same pre-scaled division."""
     from tee_optical_flow_amd.synth import speckle_sequence
     H, W = 200, 264
     yy, xx = np.mgrid[0:H, 0:W]
@@ -175,4 +176,4 @@ def test_deepflow_sector_masked_frames(deep, oracle):
     for i in range(2):
         ref = oracle.deepflow_calc(fr[i], fr[i + 1])
         assert np.array_equal(np.asarray(flows[i]).view(np.uint32), ref.view(np.uint32)) or np.array_equal(flows[i], ref), f"pair {i}"
-        assert np.isfinite(ref).all() and (np.abs(ref[~sector]) < 1e-3).mean() > 0.5      # the flat region really is (nearly) still
+        assert np.isfinite(ref).all()
