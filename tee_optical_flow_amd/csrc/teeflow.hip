@@ -703,6 +703,12 @@ int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float ome
         return nx * ny;
     };
     int shape = h->sor_rt_shape;
+    if (shape == 3 && g.w <= 62 && g.h <= 128) {
+        // a level this narrow fills at most half a wave: two bands per wave (k_df_sor_rt<.., HALF>), all sweeps in one launch
+        if (g.h <= 64) hipLaunchKernelGGL((k_df_sor_rt<4, 8, true>), dim3(1, 1, B), dim3(512), 0, s, d, g, omega, left, 0, h->sor_plain_div);
+        else hipLaunchKernelGGL((k_df_sor_rt<4, 16, true>), dim3(1, 1, B), dim3(1024), 0, s, d, g, omega, left, 0, h->sor_plain_div);
+        return left;
+    }
     const bool whole64 = g.w <= 128 && g.h <= 64, whole32 = g.w <= 128 && g.h <= 32;
     if (shape == 3) {
         shape = 1;

@@ -194,7 +194,8 @@ __device__ __forceinline__ void rt_band_store(const SorRtState<R, NB>& t, const 
 // `nsw` sweeps.  Half-sweep j only has to be right within 2 nsw - 1 - j rows of the core [ylo, yhi) (the rest of the halo has
 // done its job: what it feeds is one row nearer per half-sweep), so a band that lies wholly outside that range sits the
 // half-sweep out -- ~1/8 of the updates of a 64-row region at nsw = 5.  (No such luck in x: the halo columns are lanes.)
-template <int R, int NB, bool FAST>
+// wv: the band of this lane (wave-uniform unless the wave carries two bands), gy0 / ROWS: first row and row count of the WAVE
+template <int R, int NB, bool FAST, int ROWS = R>
 __device__ __forceinline__ void sor_rt_sweeps(SorRtState<R, NB>& t, float2 (*exT)[2][64], float2 (*exB)[2][64], int wv, int ln, float omega, int nsw, bool live,
                                               int gy0, int ylo, int yhi)
 {
@@ -204,7 +205,7 @@ __device__ __forceinline__ void sor_rt_sweeps(SorRtState<R, NB>& t, float2 (*exT
         for (int c = 0; c < 2; ++c) {
             const int st = c, sb = (R - 1 + c) & 1;            // column parity of the active pixel in the band's first / last row
             const int m = 2 * (nsw - sw) - 1 - c;
-            if (live && gy0 + R > ylo - m && gy0 < yhi + m) {
+            if (live && gy0 + ROWS > ylo - m && gy0 < yhi + m) {
                 const float2 up = exB[wv][st][ln], dn = exT[wv + 1][sb][ln];
                 if (c == 0) rt_update_rows<R, NB, 0, R, 0, FAST>(t, up, dn, omega);
                 else rt_update_rows<R, NB, 0, R, 1, FAST>(t, up, dn, omega);
@@ -217,37 +218,43 @@ __device__ __forceinline__ void sor_rt_sweeps(SorRtState<R, NB>& t, float2 (*exT
 }
 
 // grid (tiles x, tiles y, pairs), 64 * NB threads.  R even (row parity of a thread's rows must not depend on the band).
-template <int R, int NB>
+// HALF: a level at most 62 px wide uses at most 31 of a wave's 64 lanes, so each wave carries TWO bands: lanes 0-31 hold band 2w, lanes
+// 32-63 band 2w + 1 (columns 2 (lane & 31) ..).  Nothing else changes: lane 31's columns (62, 63) lie outside the image, so it carries zero
+// values and zero weights, and that is all lane 32 sees of it through the DPP shift (and vice versa).  Whole-level launches only (hl = 0,
+// grid 1 x 1): half the waves for the 25 sweeps of the small pyramid levels, which are bound by the VALU throughput of ONE CU.
+template <int R, int NB, bool HALF = false>
 __global__ __launch_bounds__(64 * NB) void k_df_sor_rt(DfBufs d, Geom g, float omega, int nsw, int hl, int plain_div)
 {
     static_assert(R % 2 == 0, "rows per band must be even");
-    constexpr int RW = 128, RH = R * NB;
-    __shared__ float2 exT[NB + 1][2][64];       // [band]: first row of the band (read by the band above); [NB] stays zero
-    __shared__ float2 exB[NB + 1][2][64];       // [band + 1]: last row of the band (read by the band below); [0] stays zero
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63, b = blockIdx.z;
+    constexpr int RW = 128, NBANDS = HALF ? 2 * NB : NB, RH = R * NBANDS;
+    __shared__ float2 exT[NBANDS + 1][2][64];   // [band]: first row of the band (read by the band above); [NBANDS] stays zero
+    __shared__ float2 exB[NBANDS + 1][2][64];   // [band + 1]: last row of the band (read by the band below); [0] stays zero
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.z;
+    const int band = HALF ? 2 * wv + (int)((threadIdx.x >> 5) & 1) : wv, ln = HALF ? threadIdx.x & 31 : threadIdx.x & 63;
     const int W = g.w, H = g.h, pitch = g.pitch;
     const int x0 = blockIdx.x * (RW - 2 * hl), y0 = blockIdx.y * (RH - 2 * hl);          // both even
-    const int gx = x0 + 2 * ln, gy0 = y0 + wv * R;
+    const int gx = x0 + 2 * ln, gy0 = y0 + band * R;
     const size_t po = (size_t)b * g.splane;
     SorRtState<R, NB> t;
-    rt_band_issue_loads(t, d, po, gy0, gx, W, H, pitch, wv > 0);
-    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, wv > 0) | plain_div;      // plain_div: tests force the plain-division path
-    exT[wv][0][ln] = make_float2(t.du[0][0], t.dv[0][0]); exT[wv][1][ln] = make_float2(t.du[0][1], t.dv[0][1]);
-    exB[wv + 1][0][ln] = make_float2(t.du[R - 1][0], t.dv[R - 1][0]); exB[wv + 1][1][ln] = make_float2(t.du[R - 1][1], t.dv[R - 1][1]);
+    rt_band_issue_loads(t, d, po, gy0, gx, W, H, pitch, band > 0);
+    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, band > 0) | plain_div;    // plain_div: tests force the plain-division path
+    exT[band][0][ln] = make_float2(t.du[0][0], t.dv[0][0]); exT[band][1][ln] = make_float2(t.du[0][1], t.dv[0][1]);
+    exB[band + 1][0][ln] = make_float2(t.du[R - 1][0], t.dv[R - 1][0]); exB[band + 1][1][ln] = make_float2(t.du[R - 1][1], t.dv[R - 1][1]);
     if (wv == 0) {
-        exT[NB][0][ln] = exT[NB][1][ln] = make_float2(0, 0);
+        exT[NBANDS][0][ln] = exT[NBANDS][1][ln] = make_float2(0, 0);
         exB[0][0][ln] = exB[0][1][ln] = make_float2(0, 0);
     }
     const bool slow = __builtin_amdgcn_readfirstlane(__syncthreads_or(bad)) != 0;      // block-uniform; also the barrier behind the LDS fill
-    const bool live = gy0 < H;                                                          // wave-uniform: a band below the image has nothing to update
+    const int gyw = y0 + (HALF ? 2 * wv : wv) * R;                                      // first row of the wave (HALF: of its upper band)
+    const bool live = gyw < H;                                                          // wave-uniform: nothing to update below the image
     // the core: at least hl pixels away from every region edge that is not the image border
     const int xlo = blockIdx.x == 0 ? 0 : x0 + hl, xhi = blockIdx.x == gridDim.x - 1 ? W : x0 + RW - hl;
     const int ylo = blockIdx.y == 0 ? 0 : y0 + hl, yhi = blockIdx.y == gridDim.y - 1 ? H : y0 + RH - hl;
     if (!slow) {
         rt_band_scale(t);
-        sor_rt_sweeps<R, NB, true>(t, exT, exB, wv, ln, omega, nsw, live, gy0, ylo, yhi);
+        sor_rt_sweeps<R, NB, true, HALF ? 2 * R : R>(t, exT, exB, band, ln, omega, nsw, live, gyw, ylo, yhi);
     } else {
-        sor_rt_sweeps<R, NB, false>(t, exT, exB, wv, ln, omega, nsw, live, gy0, ylo, yhi);
+        sor_rt_sweeps<R, NB, false, HALF ? 2 * R : R>(t, exT, exB, band, ln, omega, nsw, live, gyw, ylo, yhi);
     }
     rt_band_store(t, d, po, gy0, gx, W, H, pitch, xlo, xhi, ylo, yhi);
 }

@@ -88,6 +88,30 @@ def test_sor_plain_division_path_bit_exact(deep, oracle, shape_knob):
     assert np.array_equal(gu, ru) and np.array_equal(gv, rv)
 
 
+@pytest.mark.parametrize("plain", [0, 1])
+@pytest.mark.parametrize("shape", [(64, 62), (65, 62), (128, 61), (100, 33), (127, 60), (30, 27), (61, 2), (5, 45), (129, 62), (64, 63)])
+def test_sor_two_bands_per_wave_bit_exact(deep, oracle, shape, plain):
+    """Levels at most 62 px wide and 128 rows high run with two bands per wave (k_df_sor_rt<.., HALF>), lanes 31 / 32 being neighbours in
+    the wave but not in the image; the shapes either side of those limits take the ordinary forms."""
+    from scipy import ndimage
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(21)
+    I0 = ndimage.gaussian_filter(rng.uniform(0, 255, (h, w)), 1.2).astype(np.float32)
+    I1 = ndimage.shift(I0, (0.6, 0.9), order=1, mode="nearest").astype(np.float32)
+    u = rng.uniform(-3, 3, (h, w)).astype(np.float32)
+    v = rng.uniform(-3, 3, (h, w)).astype(np.float32)
+    ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
+    gu, gv = u.copy(), v.copy()
+    deep.set_tuning("sor_plain_div", plain)
+    try:
+        _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    finally:
+        deep.set_tuning("sor_plain_div", 0)
+    assert np.array_equal(gu, ru) and np.array_equal(gv, rv)
+
+
 @pytest.mark.parametrize("ds", [0, 1, 2])
 @pytest.mark.parametrize("shape,amp", [((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((150, 301), 2.0), ((333, 141), 1.0), ((65, 258), 3.0)])
 def test_data_and_smoothness_term_forms_bit_exact(deep, oracle, shape, amp, ds):
