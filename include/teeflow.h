@@ -214,6 +214,9 @@ int tf_device_count(void);
  * stages), "lanes" (independent engine lanes a batch is split over), "warp_margin" (pixels of flow the LDS-staged warp
  * covers around its tile: 0 = global gathers only, default 8). Results never change. */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
+/* counters of the handle for tests and tools: "coop_launches" (launches of the co-resident SOR form since the handle was made),
+ * "coop_aborts" (calls repeated with the tiled form because such a launch gave up waiting), "coop_disabled"; -1 for an unknown name */
+long long tf_dbg_counter(tf_handle* h, const char* name);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);
 int tf_dbg_df_blur(tf_handle* h, const float* src, int w, int hgt, float* dst);

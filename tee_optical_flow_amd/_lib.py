@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "tf_abi_version", "tf_device_count", "tf_default_params", "tf_create", "tf_destroy", "tf_set_param",
     "tf_get_param", "tf_set_stream", "tf_set_profile", "tf_calc_pair", "tf_calc_seq", "tf_calc_pairs", "tf_calc_pair_f32", "tf_calc_pairs_f32",
     "tf_calc_pairs_device", "tf_calc_seq_device", "tf_condition_frames", "tf_calc_seq_rgb", "tf_radlong_project", "tf_radlong_hist", "tf_radlong_select", "tf_get_iters", "tf_last_error",
-    "tf_set_tuning", "tf_default_deepflow_params", "tf_create_deepflow", "tf_dbg_df_refine", "tf_dbg_df_blur", "tf_dbg_launch_profile", "tf_dbg_strip_rule", "tf_wase_compensate", "tf_wase_compensate_device", "tf_host_alloc", "tf_host_free",
+    "tf_set_tuning", "tf_dbg_counter", "tf_default_deepflow_params", "tf_create_deepflow", "tf_dbg_df_refine", "tf_dbg_df_blur", "tf_dbg_launch_profile", "tf_dbg_strip_rule", "tf_wase_compensate", "tf_wase_compensate_device", "tf_host_alloc", "tf_host_free",
     "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
     "tf_comm_unique_id", "tf_comm_init_rank", "tf_comm_init_all", "tf_allgather_flows", "tf_allgather_flows_all", "tf_comm_wait", "tf_comm_destroy",
 ]
@@ -83,6 +83,8 @@ def load():
     L.tf_set_stream.argtypes = [vp, vp, i32]
     L.tf_set_profile.argtypes = [vp, i32]
     L.tf_set_tuning.argtypes = [vp, C.c_char_p, i32]
+    L.tf_dbg_counter.argtypes = [vp, C.c_char_p]
+    L.tf_dbg_counter.restype = C.c_longlong
     L.tf_default_deepflow_params.argtypes = [C.POINTER(TfDeepflowParams)]
     L.tf_create_deepflow.argtypes = [C.POINTER(TfDeepflowParams), i32, C.POINTER(vp)]
     L.tf_dbg_df_refine.argtypes = [vp, vp, vp, i32, i32, vp, vp]

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <map>
 #include <vector>
@@ -124,6 +125,18 @@ struct tf_handle {
                                  // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
     int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (2: four pixels per thread, 16-byte loads; 1: one pixel per
                                  // thread; 0: k_df_data then k_df_smooth)
+    int sor_coop = 1;            // DeepFlow: all sweeps of a fixed-point iteration in one launch of co-resident regions (k_df_sor_rt_coop) where a
+                                 // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form, 2 = also for batches
+                                 // so small that the tiled form would be quicker (tests)
+    int sor_coop_s = 5;          // sweeps between two exchanges of (du, dv) in that kernel (the halo is 2 x this)
+    int coop_share = 0;          // CUs (= resident 1024-thread blocks) this handle may fill with such a launch; set per call (calc_entry)
+    bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form from then on
+    bool coop_used = false;      // this call launched k_df_sor_rt_coop
+    int coop_aborts = 0;
+    long long coop_launches = 0;
+    unsigned coop_epoch = 0;     // flag value base of the next launch
+    unsigned* coop_flags = nullptr;   // one 128-byte line per resident block + the abort word behind them
+    int coop_flag_lines = 0;
     int sor_fuse = 5;            // DeepFlow: complete red-black SOR sweeps per launch of k_df_sor_rt (0 = one colour per launch, in place).
                                  // 64 pairs @512^2: 466 / 534 / 562 / 548 / 567 pairs/s for 3 / 4 / 5 / 6 / 7; 5 divides the 25 sweeps evenly
     int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
@@ -211,7 +224,7 @@ void free_buffers(tf_handle* h)
     for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
     F(h->ctl); F(h->errs); F(h->iters_dev);
     F(h->st_u8); F(h->st_flow);
-    F(h->dpyr_base); F(h->dtmp); F(h->dplanes);
+    F(h->dpyr_base); F(h->dtmp); F(h->dplanes); F(h->coop_flags); h->coop_flag_lines = 0;
     F(h->an_rad); F(h->an_lon); h->anN = 0;
     h->dnlev = h->dH = h->dW = h->dcap = 0;
     h->st_u8_bytes = h->st_flow_bytes = 0;
@@ -637,8 +650,43 @@ int df_validate(tf_handle* h, const tf_deepflow_params& p)
     return TF_OK;
 }
 
+// k_df_sor_rt_coop's meeting place: a flag line per block that can be resident (one per CU) + the abort word behind them
+int coop_ensure(tf_handle* h)
+{
+    if (h->coop_flags) return TF_OK;
+    h->coop_flag_lines = h->num_cus;
+    HIPC(h, hipMalloc(&h->coop_flags, ((size_t)h->coop_flag_lines + 1) * 128));
+    HIPC(h, hipMemsetAsync(h->coop_flags, 0, ((size_t)h->coop_flag_lines + 1) * 128, h->stream));
+    h->coop_epoch = 0;
+    return TF_OK;
+}
+// after the stream has drained: did a launch of this call give up waiting?  Then the results are void: the tiled form from now on.
+int coop_aborted(tf_handle* h, bool* aborted)
+{
+    *aborted = false;
+    if (!h->coop_used || !h->coop_flags) return TF_OK;
+    h->coop_used = false;
+    unsigned word = 0;
+    HIPC(h, hipMemcpy(&word, h->coop_flags + (size_t)h->coop_flag_lines * 32, sizeof word, hipMemcpyDeviceToHost));
+    if (!word) return TF_OK;
+    h->coop_disabled = true;
+    ++h->coop_aborts;
+    HIPC(h, hipMemset(h->coop_flags, 0, ((size_t)h->coop_flag_lines + 1) * 128));
+    *aborted = true;
+    return TF_OK;
+}
+// Two launches of co-resident regions that each count on the same CUs can wait for each other for ever (each holds CUs the other's
+// last blocks need), so at most one call per device and process may use the form at a time; its lanes split the CUs between them.
+static std::atomic<int> g_coop_busy[64];
+struct CoopClaim {
+    int dev; bool ok;
+    explicit CoopClaim(int dev_) : dev(dev_), ok(false) { int z = 0; if (dev >= 0 && dev < 64) ok = g_coop_busy[dev].compare_exchange_strong(z, 1); }
+    ~CoopClaim() { if (ok) g_coop_busy[dev].store(0); }
+};
+
 int df_ensure_alloc(tf_handle* h, int H, int W, int B)
 {
+    int rc_coop = TF_OK;
     const int mb = h->DP.max_batch > 0 ? h->DP.max_batch : DEFAULT_MAX_BATCH;
     const int want = B < mb ? B : mb;
     if (h->dH == H && h->dW == W && h->dcap >= want) return TF_OK;
@@ -657,6 +705,8 @@ int df_ensure_alloc(tf_handle* h, int H, int W, int B)
     float** slots[] = {&d.avg, &d.Iz, &d.Ix, &d.Iy, &d.Ixx, &d.Ixy, &d.Iyy, &d.Ixz, &d.Iyz, &d.A11, &d.A12, &d.A22, &d.b1, &d.b2, &d.wg,
                        &d.du, &d.dv, &d.du2, &d.dv2, &d.Wu[0], &d.Wu[1], &d.Wv[0], &d.Wv[1]};
     for (auto s_ : slots) { *s_ = p; p += pl; }
+    rc_coop = coop_ensure(h);
+    if (rc_coop) return rc_coop;
     h->dH = H; h->dW = W; h->dcap = want;
     return TF_OK;
 }
@@ -727,6 +777,24 @@ int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float ome
     return n;
 }
 
+// Co-resident form (k_df_sor_rt_coop): regions of a level and how many pairs' worth of them this handle may keep resident at once
+// (0: the level is one region, or its regions do not fit -- tiled / whole-level form)
+int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, int* ny_)
+{
+    const int hl = 2 * S;
+    if (!h->sor_coop || h->coop_disabled || !h->coop_flags || h->sor_rt_shape != 3 || h->sor_plain_div > 1 || 64 - 2 * hl < 8) return 0;
+    const int nx = g.w <= 128 ? 1 : 1 + (g.w - 128 + (128 - 2 * hl) - 1) / (128 - 2 * hl);
+    const int ny = g.h <= 64 ? 1 : 1 + (g.h - 64 + (64 - 2 * hl) - 1) / (64 - 2 * hl);
+    const int share = h->coop_share < h->coop_flag_lines ? h->coop_share : h->coop_flag_lines;
+    if (nx * ny < 2 || nx * ny > share) return 0;
+    // few pairs: the regions would leave most CUs idle for the whole fixed-point iteration; the tiled form then switches to 128 x 32
+    // regions (launch_sor_rt), ~2.5 x the blocks -- same rule here
+    const int ny32 = g.h <= 32 ? 1 : 1 + (g.h - 32 + (32 - 2 * hl) - 1) / (32 - 2 * hl);
+    if (h->sor_coop == 1 && 32 - 2 * hl >= 8 && nx * ny * B < h->num_cus && nx * ny32 * B <= 2 * h->num_cus) return 0;     // sor_coop = 2: tests
+    *nx_ = nx; *ny_ = ny;
+    return share / (nx * ny);
+}
+
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
 void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const Geom& g, int cur, int B, hipStream_t s)
 {
@@ -746,7 +814,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
         }
         int left = h->DP.sor_iterations;
-        while (h->sor_rt && fuse > 0 && left > 0) {
+        auto prof_begin = [&]() -> ProfEv* {
             ProfEv* pe = nullptr;
             if (h->profile) {
                 if (h->prof_used == h->prof_pool.size()) {
@@ -756,6 +824,31 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
                 if (h->prof_used < h->prof_pool.size()) { pe = &h->prof_pool[h->prof_used++]; (void)hipEventRecord(pe->a, s); }
             }
             ++h->iter_launches;
+            return pe;
+        };
+        int cnx = 0, cny = 0;
+        const int S = h->sor_coop_s < 1 ? 1 : (h->sor_coop_s > 8 ? 8 : h->sor_coop_s);
+        const int cpairs = h->sor_rt && fuse > 0 && left > S ? sor_coop_pairs(h, g, B, S, &cnx, &cny) : 0;
+        if (cpairs > 0) {
+            // all `left` sweeps in one launch per group of pairs; the result is in (du2, dv2) after an odd number of phases
+            const int phases = (left + S - 1) / S;
+            for (int b0 = 0; b0 < B; b0 += cpairs) {
+                const int nb = B - b0 < cpairs ? B - b0 : cpairs;
+                ProfEv* pe = prof_begin();
+                hipLaunchKernelGGL((k_df_sor_rt_coop<4, 16>), dim3(cnx, cny, nb), dim3(1024), 0, s, d, g, c.omega, left, S, h->sor_plain_div, b0,
+                                   h->coop_flags, h->coop_epoch, h->coop_flags + (size_t)h->coop_flag_lines * 32);
+                h->coop_epoch += (unsigned)phases;
+                ++h->coop_launches;
+                h->df_sor_bytes += (double)left * g.w * g.h * nb * 40.0;
+                h->df_sor_px += (double)g.w * g.h * nb;
+                if (pe) (void)hipEventRecord(pe->b, s);
+            }
+            h->coop_used = true;
+            if (phases & 1) { std::swap(d.du, d.du2); std::swap(d.dv, d.dv2); }
+            left = 0;
+        }
+        while (h->sor_rt && fuse > 0 && left > 0) {
+            ProfEv* pe = prof_begin();
             const int n = launch_sor_rt(h, d, g, B, c.omega, left, fuse > 8 ? 8 : fuse, s);
             h->df_sor_bytes += (double)n * g.w * g.h * B * 40.0;
             h->df_sor_px += (double)g.w * g.h * B;
@@ -906,6 +999,16 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
                                    (size_t)nb * h->nlev * h->P.warps * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPC(h, hipEventRecord(h->ev[3], h->stream));
         HIPC(h, hipStreamSynchronize(h->stream));
+        if (deep) {
+            bool aborted = false;
+            rc = coop_aborted(h, &aborted);
+            if (rc) return rc;
+            if (aborted) {                                       // solve this sub-batch again, tiled (what was copied out is overwritten)
+                if (overlap) HIPC(h, hipStreamSynchronize(h->copy_stream));
+                c0 -= step; --kb;
+                continue;
+            }
+        }
         float t;
         HIPC(h, hipEventElapsedTime(&t, h->ev[0], h->ev[1])); ms_h2d += t;
         HIPC(h, hipEventElapsedTime(&t, h->ev[1], h->ev[2])); ms_dev += t;
@@ -962,6 +1065,8 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     if (!h) return TF_ERR_INVALID_ARG;
     int L = h->lanes;
     while (L > 1 && n_pairs / L < 16) --L;                   // a lane needs a batch worth its launches
+    CoopClaim claim(h->is_twin || h->P.algo != TF_ALGO_DEEPFLOW ? -1 : h->dev);
+    if (!h->is_twin) h->coop_share = claim.ok ? h->num_cus : 0;
     if (L < 2 || h->is_twin || !in0 || !flow_out || (mode == MODE_PAIRS && !in1) || H < 1 || W < 1 || h->stream != h->own_stream)
         return calc_common_guarded(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
     while ((int)h->twins.size() < L - 1) {
@@ -979,6 +1084,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
+        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
@@ -990,6 +1096,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         float* fo = flow_out + (size_t)first[k] * npx * 2;
         th.emplace_back([=, &ss, &rcs] { rcs[k] = calc_common_guarded(t, mode, b0, b1, nb, H, W, scale, fo, device, &ss[k]); });
     }
+    h->coop_share = (claim.ok ? h->num_cus : 0) / L;
     rcs[0] = calc_common_guarded(h, mode, in0, in1, first[1], H, W, scale, flow_out, device, &ss[0]);
     for (auto& x : th) x.join();
     if (rcs[0]) return rcs[0];
@@ -1243,10 +1350,29 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
+    else if (n == "sor_coop") { h->sor_coop = value; if (value) { h->coop_disabled = false; for (auto* t : h->twins) t->coop_disabled = false; } }
+    else if (n == "sor_coop_s") h->sor_coop_s = value;
     else if (n == "df_fuse_ds") h->df_fuse_ds = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
     return TF_OK;
+}
+
+#ifdef TF_COOP_TIMING
+extern "C" __attribute__((visibility("default"))) int tf_dbg_coop_times(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_t), sizeof(unsigned long long) * 4 * 64);
+}
+#endif
+TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
+{
+    if (!h || !name) return -1;
+    const std::string n(name);
+    long long v = -1;
+    if (n == "coop_launches") { v = h->coop_launches; for (auto* t : h->twins) v += t->coop_launches; }
+    else if (n == "coop_aborts") { v = h->coop_aborts; for (auto* t : h->twins) v += t->coop_aborts; }
+    else if (n == "coop_disabled") { v = h->coop_disabled; for (auto* t : h->twins) v |= (long long)t->coop_disabled; }
+    return v;
 }
 
 // the strip rule of k_iter2_rows (pure host arithmetic, no device call): rows per strip and strip count for n active pairs
@@ -1886,11 +2012,17 @@ TF_API int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int 
     }
     hipError_t e = hipMemcpy2DAsync(h->df.Wu[0], (size_t)g.pitch * 4, u, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpy2DAsync(h->df.Wv[0], (size_t)g.pitch * 4, v, (size_t)w * 4, (size_t)w * 4, hgt, hipMemcpyHostToDevice, h->stream);
+    CoopClaim claim(h->dev);
+    h->coop_share = claim.ok ? h->num_cus : 0;
+    int rc = coop_ensure(h);
+    if (rc) { h->df = saved; return rc; }
     if (e == hipSuccess) {
         df_refine_level(h, fr, 0, 1, g, 0, 1, h->stream);
         e = hipStreamSynchronize(h->stream);
+        bool aborted = false;
+        if (e == hipSuccess) rc = coop_aborted(h, &aborted);
+        if (!rc && aborted) rc = fail(h, TF_ERR_HIP, "deepflow refine: the co-resident SOR launch gave up waiting for its neighbours");
     }
-    int rc = TF_OK;
     if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "deepflow refine: %s", hipGetErrorString(e));
     if (!rc) rc = dbg_down(h, u, h->df.avg, g);
     if (!rc) rc = dbg_down(h, v, h->df.Iz, g);

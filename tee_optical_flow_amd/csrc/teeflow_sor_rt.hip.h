@@ -66,7 +66,7 @@ struct SorRtState {
 // Issue the loads of a band (rows gy0 .. gy0+R-1, columns gx, gx+1) straight into the state registers, RAW: a11 / a22 land in
 // s11 / s22, the pixel weights in wx, the weights of the row above the band in wyu.  Nothing is waited for here, so a band
 // can be fetched while other bands are being swept; rt_band_setup() finishes the job.
-template <int R, int NB, int K0 = 0, int N = R>
+template <int R, int NB, int K0 = 0, int N = R, bool WITH_DUV = true>
 __device__ __forceinline__ void rt_band_issue_loads(SorRtState<R, NB>& t, const DfBufs& d, size_t po, int gy0, int gx, int W, int H, int pitch, bool has_above)
 {
     // No branch here: a lane (or row) outside the image loads from the nearest 8-byte slot inside it and rt_band_setup_raw()
@@ -78,12 +78,14 @@ __device__ __forceinline__ void rt_band_issue_loads(SorRtState<R, NB>& t, const 
         const int gy = gy0 + k < H ? gy0 + k : H - 1;
         // uniform plane base (SGPRs) + 32-bit lane offset
         const unsigned i = (unsigned)gy * (unsigned)pitch + gxc;
-        const float2 vdu = *reinterpret_cast<const float2*>(d.du + po + i), vdv = *reinterpret_cast<const float2*>(d.dv + po + i);
+        if constexpr (WITH_DUV) {
+            const float2 vdu = *reinterpret_cast<const float2*>(d.du + po + i), vdv = *reinterpret_cast<const float2*>(d.dv + po + i);
+            t.du[k][0] = vdu.x; t.du[k][1] = vdu.y; t.dv[k][0] = vdv.x; t.dv[k][1] = vdv.y;
+        }
         const float2 vw = *reinterpret_cast<const float2*>(d.wg + po + i);
         const float2 v11 = *reinterpret_cast<const float2*>(d.A11 + po + i), v12 = *reinterpret_cast<const float2*>(d.A12 + po + i);
         const float2 v22 = *reinterpret_cast<const float2*>(d.A22 + po + i);
         const float2 vb1 = *reinterpret_cast<const float2*>(d.b1 + po + i), vb2 = *reinterpret_cast<const float2*>(d.b2 + po + i);
-        t.du[k][0] = vdu.x; t.du[k][1] = vdu.y; t.dv[k][0] = vdv.x; t.dv[k][1] = vdv.y;
         t.s11[k][0] = v11.x; t.s11[k][1] = v11.y; t.s22[k][0] = v22.x; t.s22[k][1] = v22.y;
         t.a12[k][0] = v12.x; t.a12[k][1] = v12.y; t.b1[k][0] = vb1.x; t.b1[k][1] = vb1.y; t.b2[k][0] = vb2.x; t.b2[k][1] = vb2.y;
         t.wx[k][0] = vw.x; t.wx[k][1] = vw.y;
@@ -257,4 +259,177 @@ __global__ __launch_bounds__(64 * NB) void k_df_sor_rt(DfBufs d, Geom g, float o
         sor_rt_sweeps<R, NB, false, HALF ? 2 * R : R>(t, exT, exB, band, ln, omega, nsw, live, gyw, ylo, yhi);
     }
     rt_band_store(t, d, po, gy0, gx, W, H, pitch, xlo, xhi, ylo, yhi);
+}
+
+// =================================================================================================
+// All sweeps of a fixed-point iteration in ONE launch: co-resident regions that trade du, dv through memory.
+//
+// The tiled form above ends the kernel every S sweeps only because a region's halo has gone stale; the next launch loads all 8 planes
+// again although 6 of them (the linear system) have not changed.  Here every region of `nb` pairs is a block that is resident at the
+// same time (the host sizes the grid to the CUs it may use: one 1024-thread block per CU), keeps the system in registers for all the
+// sweeps and, every S sweeps ("phase"), publishes the core of (du, dv) and re-reads its region -- 8 bytes per pixel instead of 40, and
+// the wait is for the at most 8 regions it overlaps, not for the grid:
+//   * phase p reads buffer (p-1)&1 and writes its core to buffer p&1 ((du,dv) = buffer 0, (du2,dv2) = buffer 1; the cores partition
+//     the level, so a buffer is complete again after every phase).  A region overwrites buffer p&1 only after its neighbours have
+//     raised flag p-1, i.e. after they have finished reading that buffer at the start of phase p-1: no write-after-read hazard;
+//   * du, dv go through memory with agent-scope (sc1) accesses: the stores are written through, the loads do not hit lines another XCD's
+//     L2 may hold stale, and a wave's stores are acknowledged (s_waitcnt vmcnt(0)) before the block raises its flag -- no L2 write-back /
+//     invalidate (an agent-scope fence per wave costs ~200 us per meeting on this chip, tools/microbench/gridsync_probe.hip; this
+//     exchange ~1.5 us on top of the sweeps);
+//   * flags: one 128-byte line per block holding `base + phase` (base grows from launch to launch, the lines are never cleared);
+//   * every wait is bounded: a block that has polled ~0.1 s raises the launch's abort word and leaves, every other block sees the
+//     word in its own wait and leaves too; the host then repeats the solve with the tiled form.  (Cannot happen while the grid fits
+//     the CUs this handle was given; a second process on the same GPU can make it happen.)
+// Bit-identical to the tiled form by construction: same regions, same halo, same sweeps.
+__device__ __forceinline__ float2 rt_ld_sc1(const float* p)
+{
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ __forceinline__ void rt_st_sc1(float* p, float a, float b)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rt_st_sc1(float* p, float a) { __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#ifdef TF_COOP_TIMING
+__device__ unsigned long long g_coop_t[4][64];      // [block sample][event]: s_memrealtime (100 MHz) stamps of wave 0
+#define COOP_T(i) do { if (wv == 0 && ln == 0 && tslot >= 0 && (i) < 64) g_coop_t[tslot][(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define COOP_TE() do { COOP_T(te); ++te; } while (0)
+#else
+#define COOP_T(i) do { } while (0)
+#define COOP_TE() do { } while (0)
+#endif
+constexpr int RT_COOP_POLL_LIMIT = 1 << 16;      // x (64-clock sleep + one load round trip) ~ 0.1 s
+
+// the phases of one block (see k_df_sor_rt_coop); one instantiation per division form so that the loop carries ONE form of the state
+template <int R, int NB, bool FAST>
+__device__ __forceinline__ void sor_rt_coop_phases(SorRtState<R, NB>& t, float2 (*exT)[2][64], float2 (*exB)[2][64], int* gone, float* const (&bufu)[2], float* const (&bufv)[2],
+                                                   int wv, int ln, int gx, unsigned gxc, int gy0, int W, int H, int pitch, float omega, int nsw, int S,
+                                                   int xlo, int xhi, int ylo, int yhi, unsigned* __restrict__ flags, unsigned base, unsigned* __restrict__ abort_word)
+{
+    const bool live = gy0 < H;
+    const int me = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#ifdef TF_COOP_TIMING
+    const int tslot = me == 0 ? 0 : (me == (int)(gridDim.x * gridDim.y) / 2 ? 1 : (me == (int)(gridDim.x * gridDim.y * gridDim.z) - 1 ? 2 : -1));
+    int te = 2;
+#endif
+    int left = nsw;
+#pragma unroll 1
+    for (int phase = 1;; ++phase) {
+        const int n = left < S ? left : S;
+        exT[wv][0][ln] = make_float2(t.du[0][0], t.dv[0][0]); exT[wv][1][ln] = make_float2(t.du[0][1], t.dv[0][1]);
+        exB[wv + 1][0][ln] = make_float2(t.du[R - 1][0], t.dv[R - 1][0]); exB[wv + 1][1][ln] = make_float2(t.du[R - 1][1], t.dv[R - 1][1]);
+        __syncthreads();
+        COOP_TE();
+        sor_rt_sweeps<R, NB, FAST>(t, exT, exB, wv, ln, omega, n, live, gy0, ylo, yhi);
+        COOP_TE();
+        // the core goes to buffer phase & 1
+        float* pu = bufu[phase & 1]; float* pv = bufv[phase & 1];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int gy = gy0 + k;
+            if (gy < ylo || gy >= yhi || gy >= H) continue;
+            const bool w0 = gx >= xlo && gx < xhi && gx < W, w1 = gx + 1 >= xlo && gx + 1 < xhi && gx + 1 < W;
+            const unsigned i = (unsigned)gy * (unsigned)pitch + (unsigned)gx;
+            if (w0 && w1) { rt_st_sc1(pu + i, t.du[k][0], t.du[k][1]); rt_st_sc1(pv + i, t.dv[k][0], t.dv[k][1]); }
+            else if (w0) { rt_st_sc1(pu + i, t.du[k][0]); rt_st_sc1(pv + i, t.dv[k][0]); }
+            else if (w1) { rt_st_sc1(pu + i + 1, t.du[k][1]); rt_st_sc1(pv + i + 1, t.dv[k][1]); }
+        }
+        left -= n;
+        if (left <= 0) break;
+        // meet the regions this one overlaps
+        __builtin_amdgcn_s_waitcnt(0);                  // this wave's stores are acknowledged
+        COOP_TE();
+        __syncthreads();
+        COOP_TE();
+        if (wv == 0) {
+            const unsigned target = base + (unsigned)phase;
+            if (ln == 0) __hip_atomic_store(flags + (size_t)me * 32, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int q = ln < 9 ? ln : 4;
+            const int nx = (int)blockIdx.x + q % 3 - 1, ny = (int)blockIdx.y + q / 3 - 1;
+            const bool ex = nx >= 0 && nx < (int)gridDim.x && ny >= 0 && ny < (int)gridDim.y;
+            const unsigned* f = flags + (size_t)(ex ? (blockIdx.z * gridDim.y + ny) * gridDim.x + nx : me) * 32;
+            int polls = 0;
+            bool ok;
+            unsigned ab;
+            while (true) {
+                const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ab = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = __all((int)(v - target) >= 0) != 0;
+                if (ok || ab != 0 || ++polls > RT_COOP_POLL_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && ln == 0) {
+                if (ab == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *gone = 1;
+            }
+        }
+        COOP_TE();
+        __syncthreads();
+        if (*gone) return;                                // block-uniform; the host repeats the solve with the tiled form
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int gy = gy0 + k < H ? gy0 + k : H - 1;
+            const unsigned i = (unsigned)gy * (unsigned)pitch + gxc;
+            const float2 vu = rt_ld_sc1(bufu[phase & 1] + i), vv = rt_ld_sc1(bufv[phase & 1] + i);
+            const bool in0 = gy0 + k < H && gx < W, in1 = gy0 + k < H && gx + 1 < W;
+            t.du[k][0] = in0 ? vu.x : 0.f; t.dv[k][0] = in0 ? vv.x : 0.f;
+            t.du[k][1] = in1 ? vu.y : 0.f; t.dv[k][1] = in1 ? vv.y : 0.f;
+        }
+#ifdef TF_COOP_TIMING
+        if (wv == 0 && ln == 0 && tslot >= 0 && te < 64) g_coop_t[tslot][te] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(__float_as_uint(t.du[0][0]) & 0);   // after the reload has landed
+        ++te;
+#endif
+    }
+}
+
+template <int R, int NB>
+__global__ __launch_bounds__(64 * NB) void k_df_sor_rt_coop(DfBufs d, Geom g, float omega, int nsw, int S, int plain_div, int pair0,
+                                                            unsigned* __restrict__ flags, unsigned base, unsigned* __restrict__ abort_word)
+{
+    static_assert(R % 2 == 0, "rows per band must be even");
+    constexpr int RW = 128, RH = R * NB;
+    __shared__ float2 exT[NB + 1][2][64];
+    __shared__ float2 exB[NB + 1][2][64];
+    __shared__ int gone;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63, b = pair0 + blockIdx.z;
+    const int W = g.w, H = g.h, pitch = g.pitch, hl = 2 * S;
+    const int x0 = blockIdx.x * (RW - 2 * hl), y0 = blockIdx.y * (RH - 2 * hl);
+    const int gx = x0 + 2 * ln, gy0 = y0 + wv * R;
+    const size_t po = (size_t)b * g.splane;
+#ifdef TF_COOP_TIMING
+    const int me_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int tslot = me_ == 0 ? 0 : (me_ == (int)(gridDim.x * gridDim.y) / 2 ? 1 : (me_ == (int)(gridDim.x * gridDim.y * gridDim.z) - 1 ? 2 : -1));
+    COOP_T(0);
+#endif
+    SorRtState<R, NB> t;
+    rt_band_issue_loads<R, NB, 0, R, false>(t, d, po, gy0, gx, W, H, pitch, wv > 0);         // the system; every access to du, dv is sc1
+    const unsigned gxc = (unsigned)(gx < W ? gx : (W - 1) & ~1);
+    float* const bufu[2] = {d.du + po, d.du2 + po};
+    float* const bufv[2] = {d.dv + po, d.dv2 + po};
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int gy = gy0 + k < H ? gy0 + k : H - 1;
+        const unsigned i = (unsigned)gy * (unsigned)pitch + gxc;
+        const float2 vu = rt_ld_sc1(bufu[0] + i), vv = rt_ld_sc1(bufv[0] + i);
+        t.du[k][0] = vu.x; t.du[k][1] = vu.y; t.dv[k][0] = vv.x; t.dv[k][1] = vv.y;
+    }
+    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, wv > 0) | plain_div;
+    if (threadIdx.x == 0) gone = 0;
+    if (wv == 0) {
+        exT[NB][0][ln] = exT[NB][1][ln] = make_float2(0, 0);
+        exB[0][0][ln] = exB[0][1][ln] = make_float2(0, 0);
+    }
+    const bool slow = __builtin_amdgcn_readfirstlane(__syncthreads_or(bad)) != 0;
+    COOP_T(1);
+    const int xlo = blockIdx.x == 0 ? 0 : x0 + hl, xhi = blockIdx.x == gridDim.x - 1 ? W : x0 + RW - hl;
+    const int ylo = blockIdx.y == 0 ? 0 : y0 + hl, yhi = blockIdx.y == gridDim.y - 1 ? H : y0 + RH - hl;
+    if (!slow) {
+        rt_band_scale(t);
+        sor_rt_coop_phases<R, NB, true>(t, exT, exB, &gone, bufu, bufv, wv, ln, gx, gxc, gy0, W, H, pitch, omega, nsw, S, xlo, xhi, ylo, yhi, flags, base, abort_word);
+    } else {
+        sor_rt_coop_phases<R, NB, false>(t, exT, exB, &gone, bufu, bufv, wv, ln, gx, gxc, gy0, W, H, pitch, omega, nsw, S, xlo, xhi, ylo, yhi, flags, base, abort_word);
+    }
 }

@@ -166,6 +166,10 @@ class DenseFlow:
         """Implementation knobs (never change results): iter_variant, strip_blocks, probe_cadence."""
         _lib.check(self._L.tf_set_tuning(self._h, name.encode(), int(value)), self._h, "tf_set_tuning")
 
+    def counter(self, name):
+        """Debug counters of the engine (tf_dbg_counter): coop_launches, coop_aborts, coop_disabled."""
+        return int(self._L.tf_dbg_counter(self._h, name.encode()))
+
     def _finish(self, st):
         self.last_stats = st.as_dict()
 

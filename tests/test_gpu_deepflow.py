@@ -54,11 +54,13 @@ def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_
     gu, gv = u.copy(), v.copy()
     deep.set_tuning("sor_fuse", fuse)
     deep.set_tuning("sor_rt_shape", shape_knob)
+    deep.set_tuning("sor_coop", 0)                      # the tiled forms are what this test is about
     try:
         _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
     finally:
         deep.set_tuning("sor_fuse", 5)
         deep.set_tuning("sor_rt_shape", 3)
+        deep.set_tuning("sor_coop", 1)
     assert np.array_equal(gu, ru), f"u: {np.sum(gu != ru)} differ, max {np.abs(gu - ru).max()}"
     assert np.array_equal(gv, rv)
 
@@ -86,6 +88,39 @@ def test_sor_plain_division_path_bit_exact(deep, oracle, shape_knob):
         deep.set_tuning("sor_plain_div", 0)
         deep.set_tuning("sor_rt_shape", 3)
     assert np.array_equal(gu, ru) and np.array_equal(gv, rv)
+
+
+@pytest.mark.parametrize("S,plain", [(1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (5, 1), (6, 0), (7, 0), (3, 1)])
+@pytest.mark.parametrize("shape", [(150, 301), (333, 141), (97, 131), (70, 200), (65, 129), (512, 512), (200, 520), (301, 75), (139, 255)])
+def test_sor_coresident_regions_bit_exact(deep, oracle, shape, S, plain):
+    """k_df_sor_rt_coop: the 25 sweeps of a fixed-point iteration in ONE launch -- the regions of the level are resident together, keep the
+    linear system in registers and trade (du, dv) with the regions they overlap every S sweeps through memory (flags, no grid barrier).
+    Same regions, halo and arithmetic as the tiled form; checked against the oracle for every S (phases of unequal length included)."""
+    from scipy import ndimage
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(31)
+    I0 = ndimage.gaussian_filter(rng.uniform(0, 255, (h, w)), 1.4).astype(np.float32)
+    I1 = ndimage.shift(I0, (-0.5, 1.1), order=1, mode="nearest").astype(np.float32)
+    u = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    v = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
+    gu, gv = u.copy(), v.copy()
+    before = deep.counter("coop_launches")
+    deep.set_tuning("sor_coop", 2)                     # 2: also for a single pair (1 leaves that to the tiled form's 128 x 32 regions)
+    deep.set_tuning("sor_coop_s", S)
+    deep.set_tuning("sor_plain_div", plain)
+    try:
+        _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    finally:
+        deep.set_tuning("sor_coop", 1)
+        deep.set_tuning("sor_coop_s", 5)
+        deep.set_tuning("sor_plain_div", 0)
+    assert deep.counter("coop_launches") == before + 5          # one launch per fixed-point iteration: the form under test did run
+    assert deep.counter("coop_aborts") == 0
+    assert np.array_equal(gu, ru), f"u: {np.sum(gu != ru)} differ, max {np.abs(gu - ru).max()}"
+    assert np.array_equal(gv, rv)
 
 
 @pytest.mark.parametrize("plain", [0, 1])
@@ -170,6 +205,27 @@ def test_deepflow_batch_and_sequence(deep, oracle):
     fs = deep.calc_batch(fr, scale=1.5)
     for i in range(3):
         assert np.array_equal(fs[i], oracle.deepflow_calc(fr[i], fr[i + 1]) * np.float32(1.5))
+
+
+@pytest.mark.parametrize("B,lanes,S", [(5, 1, 5), (7, 1, 3), (36, 2, 5), (33, 2, 4)])
+def test_deepflow_batches_through_coresident_regions(oracle, B, lanes, S):
+    """Full solves whose larger levels run k_df_sor_rt_coop: several pairs per launch, several launches per level (the regions of a
+    level x the pairs exceed the CUs a lane may fill), one lane or two lanes that split the CUs -- first, middle and last pair against the oracle."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs
+    H, W = 150, 420                                      # 4 x 4 regions at the first level
+    I0s, I1s = speckle_pairs(range(300, 300 + B), H, W)
+    eng = T.DenseFlow(algo="deepflow", max_batch=B)
+    try:
+        eng.set_tuning("lanes", lanes)
+        eng.set_tuning("sor_coop", 2)
+        eng.set_tuning("sor_coop_s", S)
+        flows = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") > 0 and eng.counter("coop_aborts") == 0
+        for b in sorted({0, B // 2, B - 1}):
+            assert np.array_equal(flows[b], oracle.deepflow_calc(I0s[b], I1s[b])), f"pair {b}"
+    finally:
+        eng.close()
 
 
 def test_deepflow_identical_frames_zero_and_errors(deep):

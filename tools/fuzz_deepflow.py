@@ -20,7 +20,7 @@ def main():
     bad = 0
     t0 = time.time()
     for c in range(cases):
-        H = int(rng.integers(26, 150)); W = int(rng.integers(26, 180)); B = int(rng.choice([1, 2, 5, 33]))
+        H = int(rng.integers(26, 220)); W = int(rng.integers(26, 300)); B = int(rng.choice([1, 2, 5, 33]))
         I0s, I1s = speckle_pairs(range(500 * c, 500 * c + B), H, W)
         if rng.random() < 0.25:
             I1s[0] = I0s[0]
@@ -30,6 +30,10 @@ def main():
         eng.set_tuning("sor_rt_shape", shape)
         eng.set_tuning("sor_fuse", fuse)
         eng.set_tuning("df_fuse_ds", int(rng.choice([0, 1, 2, 2])))
+        coop = int(rng.choice([0, 1, 2, 2]))               # co-resident regions (2: whatever the batch size), exchanging every coop_s sweeps
+        coop_s = int(rng.choice([1, 2, 3, 4, 5, 5, 6, 7]))
+        eng.set_tuning("sor_coop", coop)
+        eng.set_tuning("sor_coop_s", coop_s)
         flows = eng.calc_pairs(I0s, I1s)
         ok = True
         for b in sorted(set([0, B - 1])):
@@ -37,9 +41,10 @@ def main():
             if not np.array_equal(flows[b], ref):
                 ok = False
                 print(f"MISMATCH case {c} pair {b}: {H}x{W} B={B}: {np.sum(flows[b] != ref)} values differ, max {np.abs(flows[b] - ref).max()}", flush=True)
-        bad += not ok
+        ok = ok and eng.counter("coop_aborts") == 0
+        print(f"case {c}: {H}x{W} B={B} shape={shape} fuse={fuse} coop={coop}/{coop_s} ({eng.counter('coop_launches')} launches) {'ok' if ok else 'FAIL'}", flush=True)
         eng.close()
-        print(f"case {c}: {H}x{W} B={B} shape={shape} fuse={fuse} {'ok' if ok else 'FAIL'}", flush=True)
+        bad += not ok
     print(f"{cases - bad}/{cases} cases identical in {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 
