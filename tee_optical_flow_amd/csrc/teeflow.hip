@@ -133,6 +133,7 @@ struct tf_handle {
     bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form from then on
     bool coop_used = false;      // this call launched k_df_sor_rt_coop
     int coop_aborts = 0;
+    int coop_test_mute = 0;      // tests: block 0 of every co-resident launch never raises its flag -> its neighbours give up -> the call is repeated tiled
     long long coop_launches = 0;
     unsigned coop_epoch = 0;     // flag value base of the next launch
     unsigned* coop_flags = nullptr;   // one 128-byte line per resident block + the abort word behind them
@@ -782,7 +783,7 @@ int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float ome
 int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, int* ny_)
 {
     const int hl = 2 * S;
-    if (!h->sor_coop || h->coop_disabled || !h->coop_flags || h->sor_rt_shape != 3 || h->sor_plain_div > 1 || 64 - 2 * hl < 8) return 0;
+    if (!h->sor_coop || h->coop_disabled || !h->coop_flags || h->sor_rt_shape != 3 || 64 - 2 * hl < 8) return 0;
     const int nx = g.w <= 128 ? 1 : 1 + (g.w - 128 + (128 - 2 * hl) - 1) / (128 - 2 * hl);
     const int ny = g.h <= 64 ? 1 : 1 + (g.h - 64 + (64 - 2 * hl) - 1) / (64 - 2 * hl);
     const int share = h->coop_share < h->coop_flag_lines ? h->coop_share : h->coop_flag_lines;
@@ -835,7 +836,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             for (int b0 = 0; b0 < B; b0 += cpairs) {
                 const int nb = B - b0 < cpairs ? B - b0 : cpairs;
                 ProfEv* pe = prof_begin();
-                hipLaunchKernelGGL((k_df_sor_rt_coop<4, 16>), dim3(cnx, cny, nb), dim3(1024), 0, s, d, g, c.omega, left, S, h->sor_plain_div, b0,
+                hipLaunchKernelGGL((k_df_sor_rt_coop<4, 16>), dim3(cnx, cny, nb), dim3(1024), 0, s, d, g, c.omega, left, S, h->sor_plain_div | (h->coop_test_mute ? 2 : 0), b0,
                                    h->coop_flags, h->coop_epoch, h->coop_flags + (size_t)h->coop_flag_lines * 32);
                 h->coop_epoch += (unsigned)phases;
                 ++h->coop_launches;
@@ -1084,7 +1085,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
+        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
@@ -1352,6 +1353,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "sor_coop") { h->sor_coop = value; if (value) { h->coop_disabled = false; for (auto* t : h->twins) t->coop_disabled = false; } }
     else if (n == "sor_coop_s") h->sor_coop_s = value;
+    else if (n == "coop_test_mute") h->coop_test_mute = value ? 1 : 0;
     else if (n == "df_fuse_ds") h->df_fuse_ds = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);

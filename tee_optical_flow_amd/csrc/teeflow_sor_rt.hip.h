@@ -307,7 +307,7 @@ constexpr int RT_COOP_POLL_LIMIT = 1 << 16;      // x (64-clock sleep + one load
 template <int R, int NB, bool FAST>
 __device__ __forceinline__ void sor_rt_coop_phases(SorRtState<R, NB>& t, float2 (*exT)[2][64], float2 (*exB)[2][64], int* gone, float* const (&bufu)[2], float* const (&bufv)[2],
                                                    int wv, int ln, int gx, unsigned gxc, int gy0, int W, int H, int pitch, float omega, int nsw, int S,
-                                                   int xlo, int xhi, int ylo, int yhi, unsigned* __restrict__ flags, unsigned base, unsigned* __restrict__ abort_word)
+                                                   int xlo, int xhi, int ylo, int yhi, unsigned* __restrict__ flags, unsigned base, unsigned* __restrict__ abort_word, bool mute)
 {
     const bool live = gy0 < H;
     const int me = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -346,7 +346,7 @@ __device__ __forceinline__ void sor_rt_coop_phases(SorRtState<R, NB>& t, float2 
         COOP_TE();
         if (wv == 0) {
             const unsigned target = base + (unsigned)phase;
-            if (ln == 0) __hip_atomic_store(flags + (size_t)me * 32, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ln == 0 && !(mute && me == 0)) __hip_atomic_store(flags + (size_t)me * 32, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int q = ln < 9 ? ln : 4;
             const int nx = (int)blockIdx.x + q % 3 - 1, ny = (int)blockIdx.y + q / 3 - 1;
             const bool ex = nx >= 0 && nx < (int)gridDim.x && ny >= 0 && ny < (int)gridDim.y;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * NB) void k_df_sor_rt_coop(DfBufs d, Geom g, fl
         const float2 vu = rt_ld_sc1(bufu[0] + i), vv = rt_ld_sc1(bufv[0] + i);
         t.du[k][0] = vu.x; t.du[k][1] = vu.y; t.dv[k][0] = vv.x; t.dv[k][1] = vv.y;
     }
-    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, wv > 0) | plain_div;
+    const int bad = rt_band_setup_raw(t, gy0, gx, W, H, wv > 0) | (plain_div & 1);     // plain_div bit 1 (tests): block 0 never raises its flag
     if (threadIdx.x == 0) gone = 0;
     if (wv == 0) {
         exT[NB][0][ln] = exT[NB][1][ln] = make_float2(0, 0);
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(64 * NB) void k_df_sor_rt_coop(DfBufs d, Geom g, fl
     const int ylo = blockIdx.y == 0 ? 0 : y0 + hl, yhi = blockIdx.y == gridDim.y - 1 ? H : y0 + RH - hl;
     if (!slow) {
         rt_band_scale(t);
-        sor_rt_coop_phases<R, NB, true>(t, exT, exB, &gone, bufu, bufv, wv, ln, gx, gxc, gy0, W, H, pitch, omega, nsw, S, xlo, xhi, ylo, yhi, flags, base, abort_word);
+        sor_rt_coop_phases<R, NB, true>(t, exT, exB, &gone, bufu, bufv, wv, ln, gx, gxc, gy0, W, H, pitch, omega, nsw, S, xlo, xhi, ylo, yhi, flags, base, abort_word, (plain_div & 2) != 0);
     } else {
-        sor_rt_coop_phases<R, NB, false>(t, exT, exB, &gone, bufu, bufv, wv, ln, gx, gxc, gy0, W, H, pitch, omega, nsw, S, xlo, xhi, ylo, yhi, flags, base, abort_word);
+        sor_rt_coop_phases<R, NB, false>(t, exT, exB, &gone, bufu, bufv, wv, ln, gx, gxc, gy0, W, H, pitch, omega, nsw, S, xlo, xhi, ylo, yhi, flags, base, abort_word, (plain_div & 2) != 0);
     }
 }

@@ -228,6 +228,34 @@ def test_deepflow_batches_through_coresident_regions(oracle, B, lanes, S):
         eng.close()
 
 
+def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_tiled(oracle):
+    """Every wait in k_df_sor_rt_coop is bounded.  With block 0 muted (it never raises its flag) its neighbours poll ~0.1 s, raise the
+    launch's abort word and leave, every other block follows, the kernel ends; the host sees the word after the solve, switches the handle
+    to the tiled form and solves the batch again -- same flows as ever, and the next call does not try again."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs
+    I0s, I1s = speckle_pairs(range(40, 43), 150, 300)
+    eng = T.DenseFlow(algo="deepflow", max_batch=3)
+    try:
+        eng.set_tuning("sor_coop", 2)
+        eng.set_tuning("coop_test_mute", 1)
+        flows = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_aborts") == 1 and eng.counter("coop_disabled") == 1
+        n = eng.counter("coop_launches")
+        for b in range(3):
+            assert np.array_equal(flows[b], oracle.deepflow_calc(I0s[b], I1s[b])), f"pair {b}"
+        flows2 = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") == n and eng.counter("coop_aborts") == 1
+        assert np.array_equal(np.asarray(flows2), np.asarray(flows))
+        eng.set_tuning("coop_test_mute", 0)
+        eng.set_tuning("sor_coop", 2)                      # setting the knob re-arms the form
+        flows3 = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") > n and eng.counter("coop_aborts") == 1
+        assert np.array_equal(np.asarray(flows3), np.asarray(flows))
+    finally:
+        eng.close()
+
+
 def test_deepflow_identical_frames_zero_and_errors(deep):
     import tee_optical_flow_amd as T
     from tee_optical_flow_amd.synth import speckle_pair
