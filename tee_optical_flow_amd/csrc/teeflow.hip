@@ -833,6 +833,10 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
         if (cpairs > 0) {
             // all `left` sweeps in one launch per group of pairs; the result is in (du2, dv2) after an odd number of phases
             const int phases = (left + S - 1) / S;
+            if (h->coop_epoch > (1u << 30)) {            // flags are compared as signed differences: start over long before a stale line could look ahead
+                (void)hipMemsetAsync(h->coop_flags, 0, (size_t)h->coop_flag_lines * 128, s);
+                h->coop_epoch = 0;
+            }
             for (int b0 = 0; b0 < B; b0 += cpairs) {
                 const int nb = B - b0 < cpairs ? B - b0 : cpairs;
                 ProfEv* pe = prof_begin();
