@@ -207,12 +207,14 @@ int tf_device_count(void);
 
 /* ---- kernel-level test hooks (dense host arrays, one image; used by tests/ to compare each kernel
  *      with the oracle bit for bit; not part of the drop-in surface) -------------------------------- */
-/* implementation knobs for experiments: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips, 2 = row strips
- * with two iterations per launch [default], 3 = three per launch where inner_iterations is a multiple of 3), "min_rows_work" (rows*pairs below which tiles are used),
- * "strip_blocks" (target blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's
- * stop reports), "sched" (1 = free-running pair scheduler for batches of >= "sched_min_pairs" pairs, 0 = lock-step
- * stages), "lanes" (independent engine lanes a batch is split over), "warp_margin" (pixels of flow the LDS-staged warp
- * covers around its tile: 0 = global gathers only, default 8). Results never change. */
+/* implementation knobs for experiments (results never change).  DualTVL1: "iter_variant" (0 = 64x16 tiles, 1 = full-width row strips,
+ * 2 = row strips with two iterations per launch [default]), "min_rows_work" (rows*pairs below which tiles are used), "strip_blocks" (target
+ * blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's stop reports), "warp_margin" (pixels of flow the
+ * LDS-staged warp covers around its tile: 0 = global gathers only, default 8).  DeepFlow: "sor_rt" (0 = one colour per launch, the plain form),
+ * "sor_fuse" (sweeps per launch of the tiled register kernel), "sor_rt_shape" (region shape; 3 = chosen per launch), "sor_coop" (1 = all sweeps
+ * of a fixed-point iteration in one launch of co-resident regions where a level needs several [default], 2 = also for batches so small that
+ * the tiled form is quicker, 0 = never), "sor_coop_s" (sweeps between two exchanges), "df_fuse_ds" (form of the data/smoothness kernel).
+ * Both: "lanes" (independent engine lanes a batch is split over). */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* counters of the handle for tests and tools: "coop_launches" (launches of the co-resident SOR form since the handle was made),
  * "coop_aborts" (calls repeated with the tiled form because such a launch gave up waiting), "coop_disabled"; -1 for an unknown name */

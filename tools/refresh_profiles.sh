@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): everything profiles/ is built from, for the CURRENT kernel build.
-#   1. rocprofv3 --kernel-trace --stats summaries of the default bench command and of its single-lane form
-#   2. python3 bench.py --pmc : the FETCH_SIZE / WRITE_SIZE passes (children of bench.py, one counter per pass) for the
+#   1. python3 bench.py --pmc : the FETCH_SIZE / WRITE_SIZE passes (children of bench.py, one counter per pass) for the
 #      DualTVL1 and the DeepFlow leg, and the JSON line that carries the traffic measured that way
-#   3. per-launch profile of the lock-step driver (tools/launch_profile.py) and the arithmetic ablation probe
-#   4. SQ / GRBM counter passes over the dominant kernels (tools/pmc_sq.sh)
+#   2. SQ / GRBM counter passes over the dominant kernels (tools/pmc_sq.sh)
+#   3. rocprofv3 --kernel-trace --stats summaries of the default bench command and of its single-lane form (they read 1 and 2)
+#   4. per-launch profile of the lock-step driver (tools/launch_profile.py) and the arithmetic ablation probe
 # Outputs under gpurun_out/prof_<tag>/ ; tools/collect_profiles.py <tag> condenses them into profiles/.
 # usage: bash tools/refresh_profiles.sh <round-tag, e.g. r03>
 set -u
@@ -22,13 +22,18 @@ run_stats() {   # name, bench args...
 timeout -k 10 900 python3 $GRAFT_REPO_ROOT/bench.py --pmc --pmc-dir $OUT/pmc_live --round-tag $TAG > $OUT/${TAG}_bench_pmc.json 2> $OUT/bench_pmc.err
 echo "bench --pmc rc=$?"
 [ -f $OUT/pmc_live/hbm_traffic.json ] && cp $OUT/pmc_live/hbm_traffic.json $GRAFT_REPO_ROOT/profiles/hbm_traffic.json
+# SQ / GRBM counters next, condensed into profiles/ right away: bench.py derives roofline.limiter from the record of THIS build
+cd $GRAFT_REPO_ROOT
+bash tools/pmc_sq.sh $TAG TVL1 > $OUT/pmc_sq_tvl1.log 2>&1; tail -2 $OUT/pmc_sq_tvl1.log
+bash tools/pmc_sq.sh $TAG deepflow > $OUT/pmc_sq_df.log 2>&1; tail -2 $OUT/pmc_sq_df.log
+python3 tools/collect_profiles.py $TAG $GRAFT_REPO_ROOT/gpurun_out/collected_$TAG > $OUT/collect0.log 2>&1
+[ -f gpurun_out/collected_$TAG/${TAG}_sq_counters.json ] && cp gpurun_out/collected_$TAG/${TAG}_sq_counters.json profiles/
+cd /tmp
 run_stats default
 run_stats lanes1 --lanes 1 --no-cpu-baseline
 cd $GRAFT_REPO_ROOT
 timeout -k 10 200 python3 tools/launch_profile.py --batch 64 > $OUT/${TAG}_launch_profile_b64.txt 2>&1; echo "launch_profile rc=$?"
 [ -x tools/microbench/ablate_probe ] && (cd tools/microbench && timeout -k 10 200 ./ablate_probe > $OUT/${TAG}_ablate_probe.txt 2>&1; echo "ablate rc=$?")
-bash tools/pmc_sq.sh $TAG TVL1 > $OUT/pmc_sq_tvl1.log 2>&1; tail -2 $OUT/pmc_sq_tvl1.log
-bash tools/pmc_sq.sh $TAG deepflow > $OUT/pmc_sq_df.log 2>&1; tail -2 $OUT/pmc_sq_df.log
 # condense on the box (the raw kernel traces and counter CSVs are tens of MB; gpurun carries at most 64 MiB back) and drop the raw files
 python3 tools/collect_profiles.py $TAG $GRAFT_REPO_ROOT/gpurun_out/collected_$TAG > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
 rm -rf $OUT/default $OUT/lanes1 $OUT/pmc_live/pmc_live_* $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_TVL1/sq? $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_deepflow/sq?
