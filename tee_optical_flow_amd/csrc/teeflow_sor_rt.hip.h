@@ -209,10 +209,28 @@ __device__ __forceinline__ void sor_rt_sweeps(SorRtState<R, NB>& t, float2 (*exT
             const int m = 2 * (nsw - sw) - 1 - c;
             if (live && gy0 + ROWS > ylo - m && gy0 < yhi + m) {
                 const float2 up = exB[wv][st][ln], dn = exT[wv + 1][sb][ln];
-                if (c == 0) rt_update_rows<R, NB, 0, R, 0, FAST>(t, up, dn, omega);
-                else rt_update_rows<R, NB, 0, R, 1, FAST>(t, up, dn, omega);
-                exT[wv][st][ln] = make_float2(t.du[0][st], t.dv[0][st]);
-                exB[wv + 1][sb][ln] = make_float2(t.du[R - 1][sb], t.dv[R - 1][sb]);
+                // Order within the half-sweep (the pixels of one colour do not depend on each other): an inner row first -- its 40
+                // instructions cover the latency of the two LDS reads every wave of the block issues right behind the barrier --, then the
+                // two edge rows and their publication, then the other inner rows, which cover the LDS writes before the next barrier.
+                // (sched_barrier: the machine scheduler would otherwise put the edge rows first and the LDS writes last again.)
+                if constexpr (R >= 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == 0) rt_update_rows<R, NB, 1, 1, 0, FAST>(t, up, dn, omega);
+                    else rt_update_rows<R, NB, 1, 1, 1, FAST>(t, up, dn, omega);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == 0) { rt_update_rows<R, NB, 0, 1, 0, FAST>(t, up, dn, omega); rt_update_rows<R, NB, R - 1, 1, 0, FAST>(t, up, dn, omega); }
+                    else { rt_update_rows<R, NB, 0, 1, 1, FAST>(t, up, dn, omega); rt_update_rows<R, NB, R - 1, 1, 1, FAST>(t, up, dn, omega); }
+                    exT[wv][st][ln] = make_float2(t.du[0][st], t.dv[0][st]);
+                    exB[wv + 1][sb][ln] = make_float2(t.du[R - 1][sb], t.dv[R - 1][sb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == 0) rt_update_rows<R, NB, 2, R - 3, 0, FAST>(t, up, dn, omega);
+                    else rt_update_rows<R, NB, 2, R - 3, 1, FAST>(t, up, dn, omega);
+                } else {
+                    if (c == 0) rt_update_rows<R, NB, 0, R, 0, FAST>(t, up, dn, omega);
+                    else rt_update_rows<R, NB, 0, R, 1, FAST>(t, up, dn, omega);
+                    exT[wv][st][ln] = make_float2(t.du[0][st], t.dv[0][st]);
+                    exB[wv + 1][sb][ln] = make_float2(t.du[R - 1][sb], t.dv[R - 1][sb]);
+                }
             }
             __syncthreads();
         }
