@@ -9,6 +9,7 @@
 //   4: plain stores / loads and the counter, no fences (the meeting alone; values may be stale)
 //   5: as 1, but no counter: every block raises its own flag (one 128-byte line each) and waits for the flags of 8 other tiles of its group
 //   6: as 1 with each group's counter on its own 4-KB page
+//   7: plain stores, ONE agent-scope release fence per block (lane 0 of wave 0, after the block's barrier) before its flag, sc1 loads
 //   2: no meeting at all (time of the stores + loads alone; the check is expected to fail)
 //   3: nothing but the compute stand-in
 // build: hipcc --offload-arch=gfx950 -O3 gridsync_probe.hip -o gridsync_probe
@@ -34,15 +35,16 @@ __global__ __launch_bounds__(1024) void k_sync(unsigned long long* buf, unsigned
         const unsigned long long val = ((unsigned long long)(i + 1) << 32) | (unsigned)(tile * 1024 + t);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (MODE == 1 || MODE >= 5) __hip_atomic_store(wr + 1024 * k, val + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (MODE == 1 || MODE == 5 || MODE == 6) __hip_atomic_store(wr + 1024 * k, val + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else wr[1024 * k] = val + k;
         }
         if (MODE == 0) __threadfence();
         if (MODE == 1 || MODE >= 5) __builtin_amdgcn_s_waitcnt(0);          // every store of this wave acknowledged
         __syncthreads();
-        if (MODE == 5) {
+        if (MODE == 5 || MODE == 7) {
             if (t < 64) {
                 unsigned* flags = counters + 4096;                       // [block][32] : one line per block
+                if (MODE == 7 && t == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (t == 0) __hip_atomic_store(flags + (size_t)(grp * T + tile) * 32, base + (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int nb = (tile + 1 + (t & 7)) % T;                  // 8 other tiles (fewer when the group is small)
                 int n = 0;
@@ -97,7 +99,7 @@ static int run(const char* name, int T, int G, int steps, int spin, int slp, uns
         hipLaunchKernelGGL(k_sync<MODE>, dim3(T, G), dim3(1024), 100 * 1024, 0, buf, counters, errs, T, steps, spin, base, slp);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
-        base += (MODE == 5) ? (unsigned)steps : (unsigned)T * steps;
+        base += (MODE == 5 || MODE == 7) ? (unsigned)steps : (unsigned)T * steps;
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
@@ -115,7 +117,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&buf, (size_t)2 * 256 * 1024 * 4 * 8));
     CK(hipMalloc(&counters, (1 << 20) * sizeof(unsigned)));
     CK(hipMalloc(&errs, 2 * sizeof(unsigned)));
-    const int shapes[][2] = {{60, 4}, {60, 2}, {21, 12}, {8, 16}};
+    const int shapes[][2] = {{60, 4}, {21, 12}};
     for (auto& sh : shapes)
         for (int spin : {0, 320}) {
             float base_ms = 0;
@@ -127,6 +129,7 @@ int main(int argc, char** argv)
             if (run<1>("agent-scope atomic data, poll every 64 clk", sh[0], sh[1], steps, spin, 0, buf, counters, errs, &base_ms)) return 1;
             if (run<6>("same, counters 4 KB apart, poll every 64 clk", sh[0], sh[1], steps, spin, 0, buf, counters, errs, &base_ms)) return 1;
             if (run<5>("own flag + 8 neighbours' flags, poll 64 clk", sh[0], sh[1], steps, spin, 0, buf, counters, errs, &base_ms)) return 1;
+            if (run<7>("plain stores + one release fence per block", sh[0], sh[1], steps, spin, 0, buf, counters, errs, &base_ms)) return 1;
             if (run<5>("own flag + 8 neighbours' flags, poll 512 clk", sh[0], sh[1], steps, spin, 1, buf, counters, errs, &base_ms)) return 1;
             if (run<1>("agent-scope atomic data, poll every 512 clk", sh[0], sh[1], steps, spin, 1, buf, counters, errs, &base_ms)) return 1;
         }
