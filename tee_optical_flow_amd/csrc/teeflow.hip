@@ -128,6 +128,8 @@ struct tf_handle {
     int sor_coop = 1;            // DeepFlow: all sweeps of a fixed-point iteration in one launch of co-resident regions (k_df_sor_rt_coop) where a
                                  // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form, 2 = also for batches
                                  // so small that the tiled form would be quicker (tests)
+    int sor_coop_min_util = 85;  // co-resident launches must be at least this full (per cent) RELATIVE to the tiled form's rounds, else the level runs
+                                 // tiled (600x800 studies: 324 pairs/s always co-resident, 357 tiled, 359 with the rule)
     int sor_coop_s = 5;          // sweeps between two exchanges of (du, dv) in that kernel (the halo is 2 x this)
     int coop_share = 0;          // CUs (= resident 1024-thread blocks) this handle may fill with such a launch; set per call (calc_entry)
     bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form from then on
@@ -792,8 +794,14 @@ int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, in
     // regions (launch_sor_rt), ~2.5 x the blocks -- same rule here
     const int ny32 = g.h <= 32 ? 1 : 1 + (g.h - 32 + (32 - 2 * hl) - 1) / (32 - 2 * hl);
     if (h->sor_coop == 1 && 32 - 2 * hl >= 8 && nx * ny * B < h->num_cus && nx * ny32 * B <= 2 * h->num_cus) return 0;     // sor_coop = 2: tests
+    // Whole pairs only: a batch goes through in ceil(B / cp) launches that each hold `share` CUs, the tiled form needs
+    // ceil(B * regions / share) rounds of blocks.  Where whole pairs leave much of the share empty (one pair of 66 regions on 128 CUs)
+    // the tiled form is quicker although it loads the system five times: co-resident only if its launches are nearly as full.
+    const int cp = share / (nx * ny);
+    const long long groups = (B + cp - 1) / cp, rounds_t = ((long long)B * nx * ny + share - 1) / share;
+    if (h->sor_coop == 1 && rounds_t * 100 < (long long)h->sor_coop_min_util * groups) return 0;
     *nx_ = nx; *ny_ = ny;
-    return share / (nx * ny);
+    return cp;
 }
 
 // one cv::VariationalRefinement::calcUV for pairs [0,B) on level geometry g: W[cur] -> (avg, Iz) = W + dW
@@ -1089,7 +1097,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
+        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
@@ -1357,6 +1365,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "sor_coop") { h->sor_coop = value; if (value) { h->coop_disabled = false; for (auto* t : h->twins) t->coop_disabled = false; } }
     else if (n == "sor_coop_s") h->sor_coop_s = value;
+    else if (n == "sor_coop_min_util") h->sor_coop_min_util = value;
     else if (n == "coop_test_mute") h->coop_test_mute = value ? 1 : 0;
     else if (n == "df_fuse_ds") h->df_fuse_ds = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);

@@ -228,6 +228,26 @@ def test_deepflow_batches_through_coresident_regions(oracle, B, lanes, S):
         eng.close()
 
 
+def test_coresident_form_is_chosen_per_level_by_how_well_it_fills_the_cus(oracle):
+    """With the default knobs a level runs co-resident only if whole pairs fill >= 85 % of the CUs the handle may use; the others run
+    tiled.  Same flows whatever the rule decides (0 = always co-resident, 101 = never)."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs
+    I0s, I1s = speckle_pairs(range(60, 66), 300, 400)
+    ref = [oracle.deepflow_calc(I0s[b], I1s[b]) for b in (0, 5)]
+    launches = {}
+    for util in (0, 85, 101):
+        eng = T.DenseFlow(algo="deepflow", max_batch=6)
+        try:
+            eng.set_tuning("sor_coop_min_util", util)
+            flows = eng.calc_pairs(I0s, I1s)
+            launches[util] = eng.counter("coop_launches")
+            assert np.array_equal(flows[0], ref[0]) and np.array_equal(flows[5], ref[1]), f"min_util {util}"
+        finally:
+            eng.close()
+    assert launches[101] == 0 and launches[0] >= launches[85] > 0, launches
+
+
 def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_tiled(oracle):
     """Every wait in k_df_sor_rt_coop is bounded.  With block 0 muted (it never raises its flag) its neighbours poll ~0.1 s, raise the
     launch's abort word and leave, every other block follows, the kernel ends; the host sees the word after the solve, switches the handle
