@@ -504,10 +504,16 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                         rec = json.load(fh).get(kern)
                 except (OSError, ValueError):
                     rec = None
-                if rec and rec.get("source_fingerprint") == kernel_source_fingerprint() and "SQ_INSTS_VALU" in rec.get("per_dispatch_mean", {}):
-                    wi = rec["per_dispatch_mean"]["SQ_INSTS_VALU"]
-                    valu.update({"source": f"profiles/{os.path.basename(f)}", "valu_wave_instructions_per_launch": wi,
-                                 "valu_lane_instructions_per_px_sweep": wi * 64.0 / units_per_launch if units_per_launch else None,
+                if rec and rec.get("source_fingerprint") == kernel_source_fingerprint() and "SQ_INSTS_VALU" in rec.get("totals_all_dispatches", {}):
+                    # the counter pass profiles whole steps of this same workload (--steps-only): all its dispatches against the
+                    # pixel-sweeps of as many steps as its dispatch count says (accepted only if that is a whole number)
+                    lps = acc["iter_launches"] / max(steps, 1)
+                    nst = rec["dispatches"] / lps if lps else 0.0
+                    whole = abs(nst - round(nst)) < 0.02 and round(nst) >= 1
+                    wi = rec["totals_all_dispatches"]["SQ_INSTS_VALU"]
+                    valu.update({"source": f"profiles/{os.path.basename(f)}", "valu_wave_instructions_all_dispatches": wi,
+                                 "dispatches_in_the_counter_pass": rec["dispatches"], "steps_in_the_counter_pass": nst,
+                                 "valu_lane_instructions_per_px_sweep": (wi * 64.0 / (round(nst) * lps * units_per_launch)) if whole and units_per_launch else None,
                                  "valu_lane_instructions_per_update_in_the_loop": 40,
                                  "valu_pipe_busy_per_simd": rec.get("derived", {}).get("valu_pipe_busy_per_simd_all_launches"),
                                  "simd_cycles_per_valu_inst_all_launches": rec.get("derived", {}).get("simd_cycles_per_valu_inst_all_launches")})

@@ -35,6 +35,7 @@ def sq_summary(tag, algo, kernel):
     n = min(len(v) for v in passes.values())
     gmax = max(p["_grid"] for v in passes.values() for p in v)
     tot, cnt = collections.defaultdict(float), collections.Counter()
+    tot_all = collections.defaultdict(float)       # every dispatch of the pass (the pass profiles exactly the timed steps: --steps-only)
     rows = []
     for i in range(n):
         row = {}
@@ -42,6 +43,9 @@ def sq_summary(tag, algo, kernel):
             row.update({k: x for k, x in v[i].items() if not k.startswith("_")})
             row["_grid"] = v[i]["_grid"]
         rows.append(row)
+        for k, x in row.items():
+            if not k.startswith("_"):
+                tot_all[k] += x
         if algo == "deepflow" and row["_grid"] < gmax // 8:
             continue                                           # (older runs: single-pair latency launches of the same kernel)
         for k, x in row.items():
@@ -50,9 +54,10 @@ def sq_summary(tag, algo, kernel):
     sys.path.insert(0, ROOT)
     from bench import kernel_source_fingerprint
     out = {"kernel": kernel, "source_fingerprint": kernel_source_fingerprint(), "dispatches": n, "command": f"tools/pmc_sq.sh {tag} {algo}  (rocprofv3 --pmc <<=5 counters per pass> --kernel-include-regex ... -- "
-                                                           "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --lanes 1 --no-deepflow" + (" --algo deepflow --batch 128)" if algo == "deepflow" else ")"),
+                                                           "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --steps-only --lanes 1 --no-deepflow" + (" --algo deepflow --batch 128)" if algo == "deepflow" else ")"),
            "units": "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
-           "totals": {k: tot[k] for k in sorted(tot)}, "per_dispatch_mean": {k: tot[k] / cnt[k] for k in sorted(tot)}}
+           "totals": {k: tot[k] for k in sorted(tot)}, "per_dispatch_mean": {k: tot[k] / cnt[k] for k in sorted(tot)},
+           "totals_all_dispatches": {k: tot_all[k] for k in sorted(tot_all)}}
     t = out["totals"]
     if "SQ_WAVE_CYCLES" in t:
         wc = t["SQ_WAVE_CYCLES"]
