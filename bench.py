@@ -570,6 +570,9 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             out["executed_outer_iterations_per_pair"] = acc["outer"] / (B * steps)
             out["data_dependence_note"] = ("pairs/s depends on how early the synthetic pairs converge (executed inner iterations per pair above, of a "
                                            "possible 7500); px_iterations_per_s does not")
+        if algo != "TVL1":
+            # the co-resident SOR form: launches since the engine was made, and calls that had to be repeated tiled because a launch gave up waiting
+            out["sor_coresident"] = {"launches": eng.counter("coop_launches"), "calls_repeated_tiled": eng.counter("coop_aborts")}
         out["collective"] = collective
         if gather_ok is not None:
             out["allgather_checksums_match"] = gather_ok
