@@ -130,6 +130,7 @@ struct tf_handle {
                                  // so small that the tiled form would be quicker (tests)
     int sor_coop_min_util = 85;  // co-resident launches must be at least this full (per cent) RELATIVE to the tiled form's rounds, else the level runs
                                  // tiled (600x800 studies: 324 pairs/s always co-resident, 357 tiled, 359 with the rule)
+    int sor_coop_small = 1;      // few pairs: co-resident 128 x 32 regions (0: the tiled form, as before)
     int sor_coop_s = 5;          // sweeps between two exchanges of (du, dv) in that kernel (the halo is 2 x this)
     int coop_share = 0;          // CUs (= resident 1024-thread blocks) this handle may fill with such a launch; set per call (calc_entry)
     bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form from then on
@@ -657,7 +658,7 @@ int df_validate(tf_handle* h, const tf_deepflow_params& p)
 int coop_ensure(tf_handle* h)
 {
     if (h->coop_flags) return TF_OK;
-    h->coop_flag_lines = h->num_cus;
+    h->coop_flag_lines = 2 * h->num_cus;          // 128 x 32 regions: two 512-thread blocks per CU
     HIPC(h, hipMalloc(&h->coop_flags, ((size_t)h->coop_flag_lines + 1) * 128));
     HIPC(h, hipMemsetAsync(h->coop_flags, 0, ((size_t)h->coop_flag_lines + 1) * 128, h->stream));
     h->coop_epoch = 0;
@@ -782,18 +783,26 @@ int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float ome
 
 // Co-resident form (k_df_sor_rt_coop): regions of a level and how many pairs' worth of them this handle may keep resident at once
 // (0: the level is one region, or its regions do not fit -- tiled / whole-level form)
-int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, int* ny_)
+int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, int* ny_, int* rows_)
 {
     const int hl = 2 * S;
-    if (!h->sor_coop || h->coop_disabled || !h->coop_flags || h->sor_rt_shape != 3 || 64 - 2 * hl < 8) return 0;
+    *rows_ = 64;
+    if (!h->sor_coop || h->coop_disabled || !h->coop_flags || h->sor_rt_shape != 3 || 64 - 2 * hl < 8 || 3 * hl > 64) return 0;
     const int nx = g.w <= 128 ? 1 : 1 + (g.w - 128 + (128 - 2 * hl) - 1) / (128 - 2 * hl);
     const int ny = g.h <= 64 ? 1 : 1 + (g.h - 64 + (64 - 2 * hl) - 1) / (64 - 2 * hl);
-    const int share = h->coop_share < h->coop_flag_lines ? h->coop_share : h->coop_flag_lines;
+    const int share = h->coop_share < h->coop_flag_lines / 2 ? h->coop_share : h->coop_flag_lines / 2;
     if (nx * ny < 2 || nx * ny > share) return 0;
-    // few pairs: the regions would leave most CUs idle for the whole fixed-point iteration; the tiled form then switches to 128 x 32
-    // regions (launch_sor_rt), ~2.5 x the blocks -- same rule here
+    // few pairs: 128 x 64 regions would leave most CUs idle for the whole fixed-point iteration.  Like the tiled form (launch_sor_rt) the
+    // co-resident one then takes 128 x 32 regions: 512-thread blocks, two per CU, ~2.5 x the blocks and half the sweep time per block
     const int ny32 = g.h <= 32 ? 1 : 1 + (g.h - 32 + (32 - 2 * hl) - 1) / (32 - 2 * hl);
-    if (h->sor_coop == 1 && 32 - 2 * hl >= 8 && nx * ny * B < h->num_cus && nx * ny32 * B <= 2 * h->num_cus) return 0;     // sor_coop = 2: tests
+    // (a region waits for the 8 regions around it, so its halo must not reach past their cores: hl <= core, i.e. 3 hl <= 32 -- S <= 5;
+    // the 64-row regions satisfy 3 hl <= 64 for every S the knob allows)
+    if (h->sor_coop != 2 && 32 - 2 * hl >= 8 && 3 * hl <= 32 && nx * ny * B < h->num_cus && nx * ny32 * B <= 2 * h->num_cus) {
+        if (h->sor_coop != 3 && !h->sor_coop_small) return 0;
+        if (nx * ny32 < 2 || nx * ny32 * B > 2 * share) return 0;
+        *nx_ = nx; *ny_ = ny32; *rows_ = 32;
+        return B;                                                       // all of them in one launch
+    }
     // Whole pairs only: a batch goes through in ceil(B / cp) launches that each hold `share` CUs, the tiled form needs
     // ceil(B * regions / share) rounds of blocks.  Where whole pairs leave much of the share empty (one pair of 66 regions on 128 CUs)
     // the tiled form is quicker although it loads the system five times: co-resident only if its launches are nearly as full.
@@ -835,9 +844,9 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             ++h->iter_launches;
             return pe;
         };
-        int cnx = 0, cny = 0;
+        int cnx = 0, cny = 0, crows = 64;
         const int S = h->sor_coop_s < 1 ? 1 : (h->sor_coop_s > 8 ? 8 : h->sor_coop_s);
-        const int cpairs = h->sor_rt && fuse > 0 && left > S ? sor_coop_pairs(h, g, B, S, &cnx, &cny) : 0;
+        const int cpairs = h->sor_rt && fuse > 0 && left > S ? sor_coop_pairs(h, g, B, S, &cnx, &cny, &crows) : 0;
         if (cpairs > 0) {
             // all `left` sweeps in one launch per group of pairs; the result is in (du2, dv2) after an odd number of phases
             const int phases = (left + S - 1) / S;
@@ -848,8 +857,12 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
             for (int b0 = 0; b0 < B; b0 += cpairs) {
                 const int nb = B - b0 < cpairs ? B - b0 : cpairs;
                 ProfEv* pe = prof_begin();
-                hipLaunchKernelGGL((k_df_sor_rt_coop<4, 16>), dim3(cnx, cny, nb), dim3(1024), 0, s, d, g, c.omega, left, S, h->sor_plain_div | (h->coop_test_mute ? 2 : 0), b0,
-                                   h->coop_flags, h->coop_epoch, h->coop_flags + (size_t)h->coop_flag_lines * 32);
+                if (crows == 32)
+                    hipLaunchKernelGGL((k_df_sor_rt_coop<4, 8>), dim3(cnx, cny, nb), dim3(512), 0, s, d, g, c.omega, left, S, h->sor_plain_div | (h->coop_test_mute ? 2 : 0), b0,
+                                       h->coop_flags, h->coop_epoch, h->coop_flags + (size_t)h->coop_flag_lines * 32);
+                else
+                    hipLaunchKernelGGL((k_df_sor_rt_coop<4, 16>), dim3(cnx, cny, nb), dim3(1024), 0, s, d, g, c.omega, left, S, h->sor_plain_div | (h->coop_test_mute ? 2 : 0), b0,
+                                       h->coop_flags, h->coop_epoch, h->coop_flags + (size_t)h->coop_flag_lines * 32);
                 h->coop_epoch += (unsigned)phases;
                 ++h->coop_launches;
                 h->df_sor_bytes += (double)left * g.w * g.h * nb * 40.0;
@@ -1097,7 +1110,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
+        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
@@ -1365,6 +1378,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "sor_coop") { h->sor_coop = value; if (value) { h->coop_disabled = false; for (auto* t : h->twins) t->coop_disabled = false; } }
     else if (n == "sor_coop_s") h->sor_coop_s = value;
+    else if (n == "sor_coop_small") h->sor_coop_small = value ? 1 : 0;
     else if (n == "sor_coop_min_util") h->sor_coop_min_util = value;
     else if (n == "coop_test_mute") h->coop_test_mute = value ? 1 : 0;
     else if (n == "df_fuse_ds") h->df_fuse_ds = value < 0 ? 0 : (value > 2 ? 2 : value);

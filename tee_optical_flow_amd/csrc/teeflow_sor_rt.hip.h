@@ -404,7 +404,7 @@ __device__ __forceinline__ void sor_rt_coop_phases(SorRtState<R, NB>& t, float2 
 }
 
 template <int R, int NB>
-__global__ __launch_bounds__(64 * NB) void k_df_sor_rt_coop(DfBufs d, Geom g, float omega, int nsw, int S, int plain_div, int pair0,
+__global__ __launch_bounds__(64 * NB, 4) void k_df_sor_rt_coop(DfBufs d, Geom g, float omega, int nsw, int S, int plain_div, int pair0,
                                                             unsigned* __restrict__ flags, unsigned base, unsigned* __restrict__ abort_word)
 {
     static_assert(R % 2 == 0, "rows per band must be even");

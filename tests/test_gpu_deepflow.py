@@ -228,6 +228,37 @@ def test_deepflow_batches_through_coresident_regions(oracle, B, lanes, S):
         eng.close()
 
 
+@pytest.mark.parametrize("S,plain", [(1, 0), (3, 0), (4, 0), (5, 0), (5, 1), (6, 0)])      # S = 6: the halo would reach past the neighbours' 8-row cores -> 128 x 64 regions
+@pytest.mark.parametrize("shape", [(150, 301), (333, 141), (97, 131), (512, 512), (200, 520), (40, 300)])
+def test_sor_coresident_small_regions_bit_exact(deep, oracle, shape, S, plain):
+    """Few pairs (here one): the co-resident form takes 128 x 32 regions -- 512-thread blocks, two per CU -- so that a single pair still
+    spreads over the chip; same exchange protocol, checked against the oracle."""
+    from scipy import ndimage
+    from tee_optical_flow_amd import _lib
+    L = _lib.load()
+    h, w = shape
+    rng = np.random.default_rng(37)
+    I0 = ndimage.gaussian_filter(rng.uniform(0, 255, (h, w)), 1.4).astype(np.float32)
+    I1 = ndimage.shift(I0, (0.8, -0.7), order=1, mode="nearest").astype(np.float32)
+    u = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    v = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    ru, rv = oracle.deepflow_variational_refine(I0, I1, u, v)
+    gu, gv = u.copy(), v.copy()
+    before = deep.counter("coop_launches")
+    deep.set_tuning("sor_coop", 3)                     # 3: the small-region form whenever the batch is small (1 lets the size rules decide)
+    deep.set_tuning("sor_coop_s", S)
+    deep.set_tuning("sor_plain_div", plain)
+    try:
+        _lib.check(L.tf_dbg_df_refine(deep._h, _ptr(I0), _ptr(I1), w, h, _ptr(gu), _ptr(gv)), deep._h)
+    finally:
+        deep.set_tuning("sor_coop", 1)
+        deep.set_tuning("sor_coop_s", 5)
+        deep.set_tuning("sor_plain_div", 0)
+    assert deep.counter("coop_launches") == before + 5 and deep.counter("coop_aborts") == 0
+    assert np.array_equal(gu, ru), f"u: {np.sum(gu != ru)} differ, max {np.abs(gu - ru).max()}"
+    assert np.array_equal(gv, rv)
+
+
 def test_coresident_form_is_chosen_per_level_by_how_well_it_fills_the_cus(oracle):
     """With the default knobs a level runs co-resident only if whole pairs fill >= 85 % of the CUs the handle may use; the others run
     tiled.  Same flows whatever the rule decides (0 = always co-resident, 101 = never)."""
@@ -240,6 +271,7 @@ def test_coresident_form_is_chosen_per_level_by_how_well_it_fills_the_cus(oracle
         eng = T.DenseFlow(algo="deepflow", max_batch=6)
         try:
             eng.set_tuning("sor_coop_min_util", util)
+            eng.set_tuning("sor_coop_small", 0)            # the small-batch form (128 x 32 regions) is not subject to this rule
             flows = eng.calc_pairs(I0s, I1s)
             launches[util] = eng.counter("coop_launches")
             assert np.array_equal(flows[0], ref[0]) and np.array_equal(flows[5], ref[1]), f"min_util {util}"

@@ -30,7 +30,7 @@ def main():
         eng.set_tuning("sor_rt_shape", shape)
         eng.set_tuning("sor_fuse", fuse)
         eng.set_tuning("df_fuse_ds", int(rng.choice([0, 1, 2, 2])))
-        coop = int(rng.choice([0, 1, 2, 2]))               # co-resident regions (2: whatever the batch size), exchanging every coop_s sweeps
+        coop = int(rng.choice([0, 1, 2, 2, 3]))            # co-resident regions (2: 128 x 64 whatever the batch size, 3: 128 x 32 for small batches), exchanging every coop_s sweeps
         coop_s = int(rng.choice([1, 2, 3, 4, 5, 5, 6, 7]))
         eng.set_tuning("sor_coop", coop)
         eng.set_tuning("sor_coop_s", coop_s)
