@@ -212,8 +212,8 @@ int tf_device_count(void);
  * blocks per tvl1_iter launch), "lag" (launches the host may run ahead of the device's stop reports), "warp_margin" (pixels of flow the
  * LDS-staged warp covers around its tile: 0 = global gathers only, default 8).  DeepFlow: "sor_rt" (0 = one colour per launch, the plain form),
  * "sor_fuse" (sweeps per launch of the tiled register kernel), "sor_rt_shape" (region shape; 3 = chosen per launch), "sor_coop" (1 = all sweeps
- * of a fixed-point iteration in one launch of co-resident regions where a level needs several [default], 2 = also for batches so small that
- * the tiled form is quicker, 0 = never), "sor_coop_s" (sweeps between two exchanges), "sor_coop_min_util" (per cent of its CUs such a launch must fill, else tiled), "df_fuse_ds" (form of the data/smoothness kernel).
+ * of a fixed-point iteration in one launch of co-resident regions where a level needs several [default], 2 = always 128x64 regions, 3 = always
+ * 128x32 regions for small batches, 0 = never), "sor_coop_small" (0 = small batches keep the tiled form), "sor_coop_s" (sweeps between two exchanges), "sor_coop_min_util" (per cent of its CUs such a launch must fill, else tiled), "df_fuse_ds" (form of the data/smoothness kernel).
  * Both: "lanes" (independent engine lanes a batch is split over). */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* counters of the handle for tests and tools: "coop_launches" (launches of the co-resident SOR form since the handle was made),
