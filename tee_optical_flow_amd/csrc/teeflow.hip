@@ -126,8 +126,9 @@ struct tf_handle {
     int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (2: four pixels per thread, 16-byte loads; 1: one pixel per
                                  // thread; 0: k_df_data then k_df_smooth)
     int sor_coop = 1;            // DeepFlow: all sweeps of a fixed-point iteration in one launch of co-resident regions (k_df_sor_rt_coop) where a
-                                 // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form, 2 = also for batches
-                                 // so small that the tiled form would be quicker (tests)
+                                 // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form,
+                                 // 2 = 128 x 64 regions whatever the batch size and however full the launches (tests), 3 = the small-batch form
+                                 // (128 x 32 regions) whenever the batch is small, sor_coop_small or not (tests)
     int sor_coop_min_util = 85;  // co-resident launches must be at least this full (per cent) RELATIVE to the tiled form's rounds, else the level runs
                                  // tiled (600x800 studies: 324 pairs/s always co-resident, 357 tiled, 359 with the rule)
     int sor_coop_small = 1;      // few pairs: co-resident 128 x 32 regions (0: the tiled form, as before)
