@@ -280,7 +280,8 @@ def test_coresident_form_is_chosen_per_level_by_how_well_it_fills_the_cus(oracle
     assert launches[101] == 0 and launches[0] >= launches[85] > 0, launches
 
 
-def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_tiled(oracle):
+@pytest.mark.parametrize("form", [2, 3])          # 128 x 64 regions / the small-batch form (128 x 32 regions, two blocks per CU)
+def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_tiled(oracle, form):
     """Every wait in k_df_sor_rt_coop is bounded.  With block 0 muted (it never raises its flag) its neighbours poll ~0.1 s, raise the
     launch's abort word and leave, every other block follows, the kernel ends; the host sees the word after the solve, switches the handle
     to the tiled form and solves the batch again -- same flows as ever, and the next call does not try again."""
@@ -289,7 +290,7 @@ def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_ti
     I0s, I1s = speckle_pairs(range(40, 43), 150, 300)
     eng = T.DenseFlow(algo="deepflow", max_batch=3)
     try:
-        eng.set_tuning("sor_coop", 2)
+        eng.set_tuning("sor_coop", form)
         eng.set_tuning("coop_test_mute", 1)
         flows = eng.calc_pairs(I0s, I1s)
         assert eng.counter("coop_aborts") == 1 and eng.counter("coop_disabled") == 1
@@ -300,7 +301,7 @@ def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_ti
         assert eng.counter("coop_launches") == n and eng.counter("coop_aborts") == 1
         assert np.array_equal(np.asarray(flows2), np.asarray(flows))
         eng.set_tuning("coop_test_mute", 0)
-        eng.set_tuning("sor_coop", 2)                      # setting the knob re-arms the form
+        eng.set_tuning("sor_coop", form)                   # setting the knob re-arms the form
         flows3 = eng.calc_pairs(I0s, I1s)
         assert eng.counter("coop_launches") > n and eng.counter("coop_aborts") == 1
         assert np.array_equal(np.asarray(flows3), np.asarray(flows))
