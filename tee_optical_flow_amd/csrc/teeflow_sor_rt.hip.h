@@ -24,6 +24,12 @@
 // edge invalidates one more ring of pixels per half-sweep, so after `nsw` sweeps everything at least hl pixels away from
 // such an edge equals what one-colour-per-launch SOR computes.  Only that core is written -- to (du2, dv2), because the
 // neighbouring regions still read (du, dv) as their halo.
+//
+// Three launch forms share the band code below:
+//   k_df_sor_rt<R,NB>            tiled: `nsw` sweeps per launch (hl = 2 nsw), or a whole level in one region (hl = 0, any number of sweeps)
+//   k_df_sor_rt<R,NB,HALF>       whole levels at most 62 px wide: two bands per wave
+//   k_df_sor_rt_coop<R,NB>       (end of this file) all sweeps of a fixed-point iteration in one launch: the regions are resident together
+//                                and trade (du, dv) with the regions they overlap every S sweeps -- the default wherever it applies
 #pragma once
 #include "teeflow_deepflow.hip.h"
 
