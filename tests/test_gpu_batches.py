@@ -106,3 +106,29 @@ def test_config3_shard_128_pairs_512(oracle):
             assert np.array_equal(got[b], ref), f"pair {b}: not bit-identical to the oracle"
     finally:
         eng.close()
+
+
+def test_config4_batch_128_pairs_512_deepflow_every_sor_form_agrees(oracle):
+    """BASELINE.json configs[3] (DeepFlow, all defaults) at the bench's batch: 128 pairs x 512^2 in one call, two lanes of 64.  The oracle needs
+    ~0.35 s per pair, so at this size the property checked over ALL 128 flows is form-independence -- the co-resident launches (the default),
+    the tiled register kernel and the one-colour-per-launch plain form must give the same bits -- and a spread sample is held against the oracle."""
+    from bench import make_inputs
+    import tee_optical_flow_amd as T
+    B, H, W = 128, 512, 512
+    I0s, I1s = make_inputs(range(B), H, W, allow_pool=False)
+    eng = T.DenseFlow(device_id=0, max_batch=B, algo="deepflow")
+    try:
+        flows = np.asarray(eng.calc_pairs(I0s, I1s)).copy()
+        assert eng.counter("coop_launches") > 1000 and eng.counter("coop_aborts") == 0
+        n = eng.counter("coop_launches")
+        eng.set_tuning("sor_coop", 0)
+        tiled = np.asarray(eng.calc_pairs(I0s, I1s))
+        assert eng.counter("coop_launches") == n
+        assert np.array_equal(flows, tiled), "co-resident and tiled SOR disagree"
+        eng.set_tuning("sor_rt", 0)
+        plain = np.asarray(eng.calc_pairs(I0s[:16], I1s[:16]))
+        assert np.array_equal(flows[:16], plain), "register-tile and plain SOR disagree"
+        for b in (0, 63, 64, 127):
+            assert np.array_equal(flows[b], oracle.deepflow_calc(I0s[b], I1s[b])), f"pair {b}: not bit-identical to the oracle"
+    finally:
+        eng.close()
