@@ -11,6 +11,7 @@
 // each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
+#include "teeflow_iter_wave.hip.h"
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
@@ -61,6 +62,7 @@ struct tf_handle {
     float* gxl[MAXLEV] = {}; float* gyl[MAXLEV] = {};   // TF_VARIANT_CUDA: centred gradient of every frame, per level
     int alloc_variant = 0;
     float *cwx = nullptr, *cwy = nullptr, *crho = nullptr;
+    float* zplane = nullptr;            // one level-0 plane of zeros
     StateBufs sb = {};
     PairCtl* ctl = nullptr;
     u64* errs = nullptr; int errstride = 0;
@@ -97,6 +99,12 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int iter_wave = 1;           // batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
+                                 // instead of k_iter2_rows; 0 = never
+    int wave_minrows = 8;        // k_iter2_wave: shortest strip (rows)
+    int wave_px = 0;             // k_iter2_wave: pixels per lane (4 / 6 / 8); 0 = the narrowest form that covers the level's width
+    int wave_pf = 0;             // k_iter2_wave: 1 = one wave per SIMD with the next row's loads in flight (three register sets), 0 = two or three waves per SIMD
+    int wave_slots = 0;          // k_iter2_wave: resident waves to size the strips for (0 = what the occupancy query says)
     int lds_pad_kb = 0;          // experiment: extra dynamic LDS per k_iter2_rows block (lowers the resident blocks per CU)
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
@@ -225,7 +233,7 @@ void free_buffers(tf_handle* h)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (int l = 0; l < MAXLEV; ++l) { F(h->pyr[l]); F(h->gxl[l]); F(h->gyl[l]); }
-    F(h->cwx); F(h->cwy); F(h->crho);
+    F(h->cwx); F(h->cwy); F(h->crho); F(h->zplane);
     for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
     F(h->ctl); F(h->errs); F(h->iters_dev);
     F(h->st_u8); F(h->st_flow);
@@ -272,6 +280,8 @@ int ensure_alloc(tf_handle* h, int H, int W, int B)
     h->alloc_variant = h->P.variant;
     const size_t pl = (size_t)h->lv[0].plane * cap * sizeof(float);
     HIPC(h, hipMalloc(&h->cwx, pl)); HIPC(h, hipMalloc(&h->cwy, pl)); HIPC(h, hipMalloc(&h->crho, pl));
+    HIPC(h, hipMalloc(&h->zplane, (size_t)h->lv[0].plane * sizeof(float)));
+    HIPC(h, hipMemsetAsync(h->zplane, 0, (size_t)h->lv[0].plane * sizeof(float), h->stream));
     for (int k = 0; k < 2; ++k) {
         HIPC(h, hipMalloc(&h->sb.u1[k], pl)); HIPC(h, hipMalloc(&h->sb.u2[k], pl));
         HIPC(h, hipMalloc(&h->sb.p11[k], pl)); HIPC(h, hipMalloc(&h->sb.p12[k], pl));
@@ -339,6 +349,37 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     const Geom& g = A.a.g;
     if (!rows_ok(h, g, B)) {      // small launches and very wide levels: tiles
         hipLaunchKernelGGL(k_iter2_tile, dim3((g.w + T2_OW - 1) / T2_OW, (g.h + T2_OH - 1) / T2_OH, B), dim3(256), 0, s, A);
+        return;
+    }
+    if (h->iter_wave && g.w <= 512 && B <= 1024) {
+        // one wave per strip: PX pixels per lane (float4 / float2 loads need PX*lanes to stay inside the padded row)
+        int px = h->wave_px;
+        if (px != 4 && px != 6 && px != 8) px = g.w <= 256 ? 4 : (g.w <= 384 && (g.w + 5) / 6 * 6 <= g.pitch ? 6 : 8);
+        if (px * 64 < g.w) px = 8;
+        if (px == 6 && (g.w + 5) / 6 * 6 > g.pitch) px = 8;
+        const bool pf = h->wave_pf != 0;
+        void (*kern)(Iter2Args, int, int) =
+            px == 4 ? (pf ? k_iter2_wave<4, true> : k_iter2_wave<4, false>) : px == 6 ? (pf ? k_iter2_wave<6, true> : k_iter2_wave<6, false>)
+                                                                                        : (pf ? k_iter2_wave<8, true> : k_iter2_wave<8, false>);
+        int slots = h->wave_slots;
+        if (slots <= 0) {
+            const size_t key = ((size_t)1 << 40) + (size_t)px * 2 + (pf ? 1 : 0);
+            auto f = h->slots_cache.find(key);
+            if (f == h->slots_cache.end()) {
+                int per_cu = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0);
+                if (per_cu < 1) per_cu = 1;
+                f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
+            }
+            slots = f->second;
+        }
+        int items = 1;
+        for (int n = 1; n <= B; ++n) {
+            int r, sn;
+            strip_rule_min(n, g.h, h->wave_minrows, slots, &r, &sn);
+            if (n * sn > items) items = n * sn;
+        }
+        hipLaunchKernelGGL(kern, dim3(items), dim3(64), 0, s, A, slots, h->wave_minrows);
         return;
     }
     int R, QX, RY, threads;
@@ -448,7 +489,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     ia.wx = h->cwx; ia.wy = h->cwy; ia.rho = h->crho; ia.sb = h->sb; ia.ctl = h->ctl; ia.err = h->errs;
     ia.errstride = h->errstride; ia.thr_q = thr_q; ia.g = g;
     ia.l_t = (float)(P.lambda * P.theta); ia.theta = (float)P.theta; ia.taut = (float)(P.tau / P.theta);
-    ia.variant = P.variant; ia.thr_d = thr_d;
+    ia.variant = P.variant; ia.thr_d = thr_d; ia.zplane = h->zplane;
     const bool cuda_variant = P.variant == TF_VARIANT_CUDA;      // one loop, no median, stops only after odd iterations
     MedArgs ma;
     ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
@@ -1113,6 +1154,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
         t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
+        t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->sor_plain_div = h->sor_plain_div; t->tile_max_w = h->tile_max_w;
@@ -1359,11 +1401,20 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
 {
     if (!h || !name) return TF_ERR_INVALID_ARG;
     const std::string n(name);
-    if (n == "iter_variant") h->iter_variant = value;
+    if (n == "iter_variant") {                      // 4 / 5 = two iterations per launch, one wave per strip where it applies (5: one wave per SIMD,
+        h->iter_wave = value >= 4 ? 1 : 0;          // the next row's loads in flight); 0 / 1 / 2 name one of the older forms explicitly
+        if (value >= 4) h->wave_pf = value == 5 ? 1 : 0;
+        h->iter_variant = value >= 4 ? 2 : value;
+    }
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
     else if (n == "lag") h->lag = value < 0 ? DEFAULT_LAG : (value < SLOT_RING / 2 ? value : SLOT_RING / 2);   // 0 = wait for every launch's report (it is published at the launch's start); unread slots must never be overwritten
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
+    else if (n == "iter_wave") h->iter_wave = value;
+    else if (n == "wave_minrows") h->wave_minrows = value < 1 ? 1 : value;
+    else if (n == "wave_px") h->wave_px = value;
+    else if (n == "wave_slots") h->wave_slots = value;
+    else if (n == "wave_pf") h->wave_pf = value ? 1 : 0;
     else if (n == "lds_pad_kb") h->lds_pad_kb = value < 0 ? 0 : value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
@@ -1388,6 +1439,12 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     return TF_OK;
 }
 
+#ifdef TF_WAVE_TIMING
+extern "C" __attribute__((visibility("default"))) int tf_dbg_wave_times(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 4 * 4096);
+}
+#endif
 #ifdef TF_COOP_TIMING
 extern "C" __attribute__((visibility("default"))) int tf_dbg_coop_times(unsigned long long* out)
 {
@@ -2091,9 +2148,9 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
         return TF_ERR_INVALID_ARG;
     HIPC(h, hipSetDevice(h->dev));
     const Geom g = make_geom(w, hgt);
-    DBuf cx, cy, cr, s[12];
+    DBuf cx, cy, cr, cz, s[12];
     int rc;
-    if ((rc = dbg_up(h, cx, I1wx, g)) || (rc = dbg_up(h, cy, I1wy, g)) || (rc = dbg_up(h, cr, rho_c, g))) return rc;
+    if ((rc = dbg_up(h, cx, I1wx, g)) || (rc = dbg_up(h, cy, I1wy, g)) || (rc = dbg_up(h, cr, rho_c, g)) || (rc = dbg_up(h, cz, nullptr, g))) return rc;
     float* hostp[6] = {u1, u2, p11, p12, p21, p22};
     for (int k = 0; k < 6; ++k) {
         if ((rc = dbg_up(h, s[2 * k], hostp[k], g)) || (rc = dbg_up(h, s[2 * k + 1], nullptr, g))) return rc;
@@ -2104,7 +2161,7 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     HIPC(h, hipMalloc(&errs, (size_t)(nsteps + 1) * sizeof(u64)));
     HIPC(h, hipMemsetAsync(errs, 0, (size_t)(nsteps + 1) * sizeof(u64), h->stream));
     IterArgs ia = {};
-    ia.wx = cx.p; ia.wy = cy.p; ia.rho = cr.p;
+    ia.wx = cx.p; ia.wy = cy.p; ia.rho = cr.p; ia.zplane = cz.p;
     for (int k = 0; k < 2; ++k) {
         ia.sb.u1[k] = s[0 + k].p; ia.sb.u2[k] = s[2 + k].p; ia.sb.p11[k] = s[4 + k].p;
         ia.sb.p12[k] = s[6 + k].p; ia.sb.p21[k] = s[8 + k].p; ia.sb.p22[k] = s[10 + k].p;

@@ -584,6 +584,7 @@ struct IterArgs {
     int B;
     int variant;      // 0 = cv2.optflow CPU DualTVL1; 1 = cv2.cuda.OpticalFlowDual_TVL1 stop rule
     double thr_d;     // epsilon^2 * area in double: the CUDA class keeps scaledEpsilon, error and prevError in double (variant 1)
+    const float* zplane;   // a level-0 plane of zeros (k_iter2_wave reads the dual variable from it at the first launch of a level)
 };
 
 // Block 0 / wave 0 tells the host how many of the B pairs enter iteration `it` active, through fine-grained
@@ -1141,17 +1142,22 @@ __device__ __forceinline__ int pair_mode(const u64* e, int it, int total, double
 // iterate (`n`): one round of at most `slots` resident blocks (slots = CUs x blocks per CU), each marching a strip that is
 // as long as that allows -- a lock-step batch loses a third of its time otherwise (a launch with 1024 blocks on 768 slots
 // takes two rounds, one with 300 takes as long as one with 768).  Returns rows per strip and the strip count.
-TF_HD inline void strip_rule(int n, int H, int RY, int slots, int* R, int* S)
+TF_HD inline void strip_rule_min(int n, int H, int minrows, int slots, int* R, int* S)
 {
     if (n < 1) n = 1;
+    if (minrows < 1) minrows = 1;
     const int k = (n + slots - 1) / slots;                 // rounds
     int s = (int)(((long long)k * slots) / n);
-    const int smax = H / (4 * RY) > 0 ? H / (4 * RY) : 1;  // at least 4 steps per strip (3 halo rows each)
+    const int smax = H / minrows > 0 ? H / minrows : 1;    // no strip shorter than `minrows` rows (each pays ~3 halo rows)
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     int r = (H + s - 1) / s;
     *R = r;
     *S = (H + r - 1) / r;
+}
+TF_HD inline void strip_rule(int n, int H, int RY, int slots, int* R, int* S)
+{
+    strip_rule_min(n, H, 4 * RY, slots, R, S);            // at least 4 steps per strip
 }
 
 struct Iter2Args {

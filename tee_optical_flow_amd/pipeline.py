@@ -116,7 +116,13 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
         if save_mask_subset is not None:
             raise ConfigurationError("In mode=otsu, save_mask_subset must be None")
     if nparr is None:
-        raise DICOMReadError(f"Failed to read DICOM file: {dcm_path} (pydicom is not available here; pass nparr=)")
+        # the reference's own call shape, process_video(dcm_path, save_path, ...) (:519-531): read the study file.  `.dcm` needs
+        # pydicom (DICOMReadError without it, like a failed _read_dicom_file); `.npy` / `.npz` are the offline injection formats.
+        nparr, md_file, pid_file, hr_file = read_study(dcm_path)
+        if metadata is None:
+            metadata = md_file
+        patient_id = patient_id or pid_file
+        heart_rate = heart_rate or hr_file
     if not no_saliency:
         raise OpticalFlowCalculationError("cv2.saliency preprocessing is not available; use no_saliency=True "
                                           "(what the reference's own CLI runs, calculate_optical_flow.py:737)")
@@ -148,9 +154,17 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
     finally:
         if own:
             model.close()
+    # waveforms (reference :602-620): loaded and validated by the reference's rules unless the caller injected a result dict;
+    # without a valid ECG and a valid arterial waveform the whole block is dropped (waveforms_present = False)
+    waveform_results = {}
+    if include_waveforms:
+        from .waveforms import load_all_waveforms, waveforms_to_write
+        waveform_results = waveforms if waveforms is not None else load_all_waveforms(dcm_path, waveform_folder, config, verbose)
+        if not waveforms_to_write(waveform_results):
+            include_waveforms = False
     if save_path is not None:
-        job = (save_path, flow_arr, nparr, mask_dict, metadata, waveforms or {}, patient_id, heart_rate,
-               config, mode, no_saliency, include_waveforms and bool(waveforms), save_mask_subset)
+        job = (save_path, flow_arr, nparr, mask_dict, metadata, waveform_results, patient_id, heart_rate,
+               config, mode, no_saliency, include_waveforms, save_mask_subset)
         if _defer_save is not None:
             _defer_save(job)                      # process_folder: the writer thread takes it while the next study is solved
         else:
@@ -314,9 +328,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 nparr, md, pid, hr, masks_ahead = mine_fut.result()
                 if model is None:
                     model = flow_model if flow_model is not None else make_flow_model(OF_algo, config, device_id)
-                waveforms = None
-                if include_waveforms:
-                    waveforms = _load_waveforms(waveform_folder, stem)
+                waveforms = None                                       # process_video loads and validates them (reference :602-620)
                 process_video(os.path.join(dcm_folder, filename), save_path, segmentor_model, verbose=verbose, mode=mode,
                               bkgd_comp=bkgd_comp, flipLR=flipLR, no_saliency=no_saliency, OF_algo=OF_algo,
                               save_mask_subset=save_mask_subset, include_waveforms=include_waveforms, waveform_folder=waveform_folder,
@@ -335,17 +347,3 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
         if own and model is not None:
             model.close()
     return errors
-
-
-def _load_waveforms(folder, stem):
-    """`<stem>_{II,ART,ABP,PAP,CVP}.npy` as (exists, array) pairs; validation thresholds stay with the reference's
-    waveform_loader (out of scope here) -- present files are passed through."""
-    out = {}
-    for key, names in (("ecg", ("II",)), ("art", ("ART", "ABP")), ("pap", ("PAP",)), ("cvp", ("CVP",))):
-        out[key] = (False, None)
-        for n in names:
-            p = os.path.join(folder, f"{stem}_{n}.npy")
-            if os.path.exists(p):
-                out[key] = (True, np.load(p, allow_pickle=False))
-                break
-    return out

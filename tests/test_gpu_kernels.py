@@ -89,23 +89,23 @@ def test_median_bit_exact(engine, oracle, shape, ksize):
 
 @pytest.mark.parametrize("shape", [(64, 64), (97, 131), (210, 210), (15, 60), (16, 61), (31, 121), (512, 512), (3, 1021)])
 @pytest.mark.parametrize("pzero", [0, 1])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
     """k steps of the fused tvl1_iter kernel == k oracle iterations (state AND exact error sums), for all four
     kernel forms: 64x16 tiles, full-width row strips, row strips with two iterations per launch, tiles with two
     iterations per launch (variant 3 = variant 2 on a launch too small for the strips)."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
-    engine.set_tuning("iter_variant", min(variant, 2))
-    engine.set_tuning("min_rows_work", 0 if variant < 3 else 1 << 30)   # strips even for this single small image | tiles
+    engine.set_tuning("iter_variant", variant if variant >= 4 else min(variant, 2))
+    engine.set_tuning("min_rows_work", 0 if variant != 3 else 1 << 30)   # strips even for this single small image | tiles
     try:
         _iterate_case(engine, oracle, L, shape, pzero)
     finally:
-        engine.set_tuning("iter_variant", 2)
+        engine.set_tuning("iter_variant", 4)
         engine.set_tuning("min_rows_work", 8192)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant):
     """The dual/primal updates where real echo frames put them: next to exactly-black regions the flow and the dual
     variable decay geometrically through 1e-30 into the denormal range.  State, warp constants and rho are scaled by
@@ -129,8 +129,8 @@ def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant
     wx[40:50] = rng.uniform(-20, 20, (10, w)).astype(np.float32)     # ordinary gradients over tiny flow
     wy[40:50] = rng.uniform(-20, 20, (10, w)).astype(np.float32)
     grad = wx * wx + wy * wy
-    engine.set_tuning("iter_variant", min(variant, 2))
-    engine.set_tuning("min_rows_work", 0 if variant < 3 else 1 << 30)
+    engine.set_tuning("iter_variant", variant if variant >= 4 else min(variant, 2))
+    engine.set_tuning("min_rows_work", 0 if variant != 3 else 1 << 30)
     try:
         nsteps = 6
         ref = oracle.iterate(wx, wy, grad, rho, u1, u2, *p, nsteps)
@@ -139,7 +139,7 @@ def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant
         _lib.check(L.tf_dbg_iterate(engine._h, _ptr(wx), _ptr(wy), _ptr(rho), *[_ptr(a) for a in st], w, h, nsteps, 0,
                                     _ptr(err)), engine._h)
     finally:
-        engine.set_tuning("iter_variant", 2)
+        engine.set_tuning("iter_variant", 4)
         engine.set_tuning("min_rows_work", 8192)
     for n, a, r in zip(["u1", "u2", "p11", "p12", "p21", "p22"], st, ref[:6]):
         bad = a.view(np.uint32) != r.view(np.uint32)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--no-profile", action="store_true", help="no HIP events around the launches: wall time only (what the bench's headline measures)")
     ap.add_argument("configs", nargs="*", default=["iter_variant=0", "iter_variant=1"])
     a = ap.parse_args()
     import torch
@@ -36,7 +37,7 @@ def main():
             for kv in c.split(","):
                 k, v = kv.split("=")
                 eng.set_tuning(k, int(v))
-            eng.set_profile(1)
+            eng.set_profile(0 if a.no_profile else 1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             st = eng.calc_pairs_device(p0, p1, B, H, W, flow.data_ptr())
@@ -46,7 +47,7 @@ def main():
             if ref is None:
                 ref = f
             same = bool(np.array_equal(ref, f))
-            res[c].append((dt * 1e3, st["iter_ms"], st["iter_bytes"] / 1e9 / (st["iter_ms"] / 1e3), st["iter_launches"], same))
+            res[c].append((dt * 1e3, st["iter_ms"], st["iter_bytes"] / 1e9 / max(st["iter_ms"] / 1e3, 1e-9), st["iter_launches"], same))
     import hashlib
     print("lib", os.environ.get("TEEFLOW_LIB", "default"), "flow sha1", hashlib.sha1(ref.tobytes()).hexdigest()[:16])
     for c, v in res.items():
