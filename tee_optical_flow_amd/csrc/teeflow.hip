@@ -12,6 +12,7 @@
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
 #include "teeflow_iter_wave.hip.h"
+#include "teeflow_iter3_wave.hip.h"
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
@@ -99,10 +100,11 @@ struct tf_handle {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
-    int iter_wave = 1;           // batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
+    int iter_wave = 0;           // 1: batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
                                  // instead of k_iter2_rows; 0 = never
     int wave_minrows = 8;        // k_iter2_wave: shortest strip (rows)
     int wave_px = 0;             // k_iter2_wave: pixels per lane (4 / 6 / 8); 0 = the narrowest form that covers the level's width
+    int iter_k3 = 0;             // 1: THREE iterations per launch (k_iter3_wave) wherever k_iter2_wave applies and inner_iterations is a multiple of 3
     int wave_pf = 0;             // k_iter2_wave: 1 = one wave per SIMD with the next row's loads in flight (three register sets), 0 = two or three waves per SIMD
     int wave_slots = 0;          // k_iter2_wave: resident waves to size the strips for (0 = what the occupancy query says)
     int lds_pad_kb = 0;          // experiment: extra dynamic LDS per k_iter2_rows block (lowers the resident blocks per CU)
@@ -343,6 +345,15 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
     *R = ry * (int)n;
 }
 
+// pixels per lane of the one-wave-per-strip kernels: the narrowest form that covers the level (float4 / float2 loads must stay inside the padded row)
+int wave_px(const tf_handle* h, const Geom& g)
+{
+    int px = h->wave_px;
+    if (px != 4 && px != 6 && px != 8) px = g.w <= 256 ? 4 : (g.w <= 384 && (g.w + 5) / 6 * 6 <= g.pitch ? 6 : 8);
+    if (px * 64 < g.w) px = 8;
+    if (px == 6 && (g.w + 5) / 6 * 6 > g.pitch) px = 8;
+    return px;
+}
 // launch one two-iteration tvl1_iter step (k_iter2_rows)
 void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int active_hint = 0)
 {
@@ -353,10 +364,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     }
     if (h->iter_wave && g.w <= 512 && B <= 1024) {
         // one wave per strip: PX pixels per lane (float4 / float2 loads need PX*lanes to stay inside the padded row)
-        int px = h->wave_px;
-        if (px != 4 && px != 6 && px != 8) px = g.w <= 256 ? 4 : (g.w <= 384 && (g.w + 5) / 6 * 6 <= g.pitch ? 6 : 8);
-        if (px * 64 < g.w) px = 8;
-        if (px == 6 && (g.w + 5) / 6 * 6 > g.pitch) px = 8;
+        const int px = wave_px(h, g);
         const bool pf = h->wave_pf != 0;
         void (*kern)(Iter2Args, int, int) =
             px == 4 ? (pf ? k_iter2_wave<4, true> : k_iter2_wave<4, false>) : px == 6 ? (pf ? k_iter2_wave<6, true> : k_iter2_wave<6, false>)
@@ -411,6 +419,39 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
         return;
     }
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
+}
+
+// three iterations per launch: does this stage qualify?  (levels up to 512 px wide, a batch worth the strips, inner % 3 == 0 so that
+// the median cadence stays on a pass boundary, the CPU variant's stop rule)
+bool three_ok(const tf_handle* h, const Geom& g, int B, int inner)
+{
+    return h->iter_k3 && h->iter_wave && h->iter_variant >= 2 && h->P.variant == TF_VARIANT_CPU && inner % 3 == 0 && g.w <= 512 && B <= 1024 && rows_ok(h, g, B);
+}
+// launch one three-iteration pass (k_iter3_wave); the caller has checked three_ok()
+void launch_iter3(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
+{
+    const Geom& g = A.a.g;
+    const int px = wave_px(h, g);
+    void (*kern)(Iter2Args, int, int) = px == 4 ? k_iter3_wave<4> : (px == 6 ? k_iter3_wave<6> : k_iter3_wave<8>);
+    int slots = h->wave_slots;
+    if (slots <= 0) {
+        const size_t key = ((size_t)3 << 40) + (size_t)px;
+        auto f = h->slots_cache.find(key);
+        if (f == h->slots_cache.end()) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0);
+            if (per_cu < 1) per_cu = 1;
+            f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
+        }
+        slots = f->second;
+    }
+    int items = 1;
+    for (int n = 1; n <= B; ++n) {
+        int r, sn;
+        strip_rule_min(n, g.h, h->wave_minrows, slots, &r, &sn);
+        if (n * sn > items) items = n * sn;
+    }
+    hipLaunchKernelGGL(kern, dim3(items), dim3(64), 0, s, A, slots, h->wave_minrows);
 }
 
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
@@ -496,6 +537,54 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
+    if (!cuda_variant && three_ok(h, g, B, inner)) {
+        // three iterations per launch; pass index it = 0,3,..,total (the last one can only hold REPLAY strips)
+        int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
+        bool stop = false;
+        unsigned checked = h->launch_seq;
+        for (int it = 0; it <= total && !stop; it += 3) {
+            if (it < total && it % inner == 0 && P.median_filtering > 1) {
+                ma.it = it; ma.utog = utog;
+                ProfEv* pm = h->profile ? prof_next(h) : nullptr;
+                if (pm) { pm->level = -5; HIPC(h, hipEventRecord(pm->a, s)); }
+                if (P.median_filtering == 5) hipLaunchKernelGGL(k_median3<5>, gm, dim3(256), 0, s, ma, total);
+                else hipLaunchKernelGGL(k_median3<3>, gm, dim3(256), 0, s, ma, total);
+                if (pm) HIPC(h, hipEventRecord(pm->b, s));
+                ++utog;
+            }
+            const unsigned q = h->launch_seq++;
+            h->slots_host[q % SLOT_RING] = -1;
+            Iter2Args A3;
+            A3.a = ia;
+            A3.a.host_slot = h->slots_dev + q % SLOT_RING;
+            A3.a.it = it; A3.a.utog = utog; A3.a.ptog = ptog; A3.a.pzero = (wi == 0 && it == 0) ? 1 : 0;
+            A3.utog_prev = utog_prev; A3.ptog_prev = ptog_prev; A3.pzero_prev = pzero_prev; A3.total = total;
+            ProfEv* pe = h->profile ? prof_next(h) : nullptr;
+            if (pe) { pe->level = l; pe->warp = wi; pe->it = it; HIPC(h, hipEventRecord(pe->a, s)); }
+            launch_iter3(h, A3, B, s);
+            if (pe) HIPC(h, hipEventRecord(pe->b, s));
+            ++h->iter_launches;
+            utog_prev = utog; ptog_prev = ptog; pzero_prev = A3.a.pzero;
+            ++utog; ++ptog;
+            while (checked <= q) {
+                int v = h->slots_host[checked % SLOT_RING];
+                if (v < 0) {
+                    if (q - checked < (unsigned)h->lag) break;
+                    const double t0 = now_ms();
+                    while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
+                        if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "tvl1_iter launch %u never reported (GPU hang?)", checked);
+                        if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
+                            return fail(h, TF_ERR_HIP, "stream drained but launch %u did not report", checked);
+                    }
+                }
+                ++checked;
+                if (v == 0) { stop = true; break; }
+            }
+        }
+        hipLaunchKernelGGL(k_stage_end3, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
+                           total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
+        return TF_OK;
+    }
     const bool two = cuda_variant || (h->iter_variant >= 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
@@ -1154,7 +1243,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
         t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
-        t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf;
+        t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf; t->iter_k3 = h->iter_k3;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->sor_plain_div = h->sor_plain_div; t->tile_max_w = h->tile_max_w;
@@ -1401,9 +1490,10 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
 {
     if (!h || !name) return TF_ERR_INVALID_ARG;
     const std::string n(name);
-    if (n == "iter_variant") {                      // 4 / 5 = two iterations per launch, one wave per strip where it applies (5: one wave per SIMD,
-        h->iter_wave = value >= 4 ? 1 : 0;          // the next row's loads in flight); 0 / 1 / 2 name one of the older forms explicitly
-        if (value >= 4) h->wave_pf = value == 5 ? 1 : 0;
+    if (n == "iter_variant") {                      // 4 / 5 / 6 = one wave per strip where it applies (4: two or three waves per SIMD; 5: one wave per SIMD
+        h->iter_wave = value >= 4 ? 1 : 0;          // with the next row's loads in flight; 6: that with THREE iterations per launch where inner % 3 == 0);
+        if (value >= 4) h->wave_pf = value >= 5 ? 1 : 0;   // 0 / 1 / 2 name one of the older forms explicitly
+        h->iter_k3 = value == 6 ? 1 : 0;
         h->iter_variant = value >= 4 ? 2 : value;
     }
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
@@ -1440,6 +1530,10 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
 }
 
 #ifdef TF_WAVE_TIMING
+extern "C" __attribute__((visibility("default"))) int tf_dbg_step_times(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_t), sizeof(unsigned long long) * 2 * 96);
+}
 extern "C" __attribute__((visibility("default"))) int tf_dbg_wave_times(unsigned long long* out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 4 * 4096);
@@ -2170,7 +2264,14 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
     const bool two = h->iter_variant == 2 && (rows_ok(h, g, 1) || h->tile2) && nsteps % 2 == 0;
     int launches = 0;
-    if (two) {
+    if (three_ok(h, g, 1, 3) && nsteps % 3 == 0 && nsteps > 0) {
+        for (int it = 0; it < nsteps; it += 3, ++launches) {
+            Iter2Args A3;
+            A3.a = ia; A3.a.it = it; A3.a.utog = launches; A3.a.ptog = launches; A3.a.pzero = (p_is_zero && it == 0) ? 1 : 0;
+            A3.utog_prev = A3.ptog_prev = A3.pzero_prev = 0; A3.total = nsteps;
+            launch_iter3(h, A3, 1, h->stream);
+        }
+    } else if (two) {
         for (int it = 0; it < nsteps; it += 2, ++launches) {
             Iter2Args A2;
             A2.a = ia; A2.a.it = it; A2.a.utog = launches; A2.a.ptog = launches; A2.a.pzero = (p_is_zero && it == 0) ? 1 : 0;

@@ -173,74 +173,29 @@ __device__ __forceinline__ void wv_issue(const WvRows& k, const WvPlanes& g, int
 
 // ---- the prefetch form's landing zone -------------------------------------------------------------------------------------------
 // One wave per SIMD owns 512 registers, but the VALU reads only the 256 architectural ones.  The other half takes the loads of the
-// NEXT row: global_load writes accumulation registers directly, nothing waits for them while the current row is worked on, and at
-// the end of the step they move to the set that held row y-1 (v_accvgpr_read, one per value).  hipcc cannot be talked into this
-// (its allocator copies in-flight destinations between register files and waits for them at once), hence the inline assembly; the
-// compiler does not see these loads, so the wait is written here too (wv_land_wait).
-typedef float f4 __attribute__((ext_vector_type(4)));
-template <int PX> struct WvLand { typename std::conditional<PX % 4 == 0, f4, f2>::type v[9][WvPark<PX>::NV]; };
-
-__device__ __forceinline__ void wv_land_ld(f4& d, const float* base, unsigned boff, int q)
-{
-    if (q == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(d) : "v"(boff), "s"(base) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=a"(d) : "v"(boff), "s"(base) : "memory");
-}
-__device__ __forceinline__ void wv_land_ld(f2& d, const float* base, unsigned boff, int q)
-{
-    if (q == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "=a"(d) : "v"(boff), "s"(base) : "memory");
-    else if (q == 1) asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=a"(d) : "v"(boff), "s"(base) : "memory");
-    else asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=a"(d) : "v"(boff), "s"(base) : "memory");
-}
-template <int PX>
-__device__ __forceinline__ void wv_land_issue(const WvRows& k, const WvPlanes& g, int y, WvLand<PX>& L)
-{
-    const unsigned boff = (unsigned)(y * k.pitch + k.x) * 4u;
-    const float* base[9] = {g.gu1, g.gu2, g.gwx, g.gwy, g.grh, g.g11, g.g12, g.g21, g.g22};
-#pragma unroll
-    for (int p = 0; p < 9; ++p)
-#pragma unroll
-        for (int q = 0; q < WvPark<PX>::NV; ++q) wv_land_ld(L.v[p][q], base[p], boff, q);
-}
-// Wait for the landing zone.  MEASURED ON gfx950: a wave's stores can retire before OLDER loads of the same wave have returned, so
-// "vmcnt(<stores issued since>)" does NOT mean the loads are there (results differed on full-size batches; hipcc's own waits never
-// rely on that order either way round in these kernels).  The wait is therefore vmcnt(0), placed BEFORE the step's stores go out: all
-// that is outstanding then is the landing zone itself and the previous step's stores, which have had a whole step to complete.
-template <int PX>
-__device__ __forceinline__ void wv_land_wait(WvLand<PX>& L)
-{
-    constexpr int NV = WvPark<PX>::NV;
-    static_assert(NV <= 3, "operand count");
-    // 9 planes x NV values <= 27 operands, tied in and out: nothing that reads them can move above the wait
-    if constexpr (NV == 1)
-        asm volatile("s_waitcnt vmcnt(0)" : "+a"(L.v[0][0]), "+a"(L.v[1][0]), "+a"(L.v[2][0]), "+a"(L.v[3][0]), "+a"(L.v[4][0]), "+a"(L.v[5][0]),
-                     "+a"(L.v[6][0]), "+a"(L.v[7][0]), "+a"(L.v[8][0]) : : "memory");
-    else if constexpr (NV == 2)
-        asm volatile("s_waitcnt vmcnt(0)" : "+a"(L.v[0][0]), "+a"(L.v[0][1]), "+a"(L.v[1][0]), "+a"(L.v[1][1]), "+a"(L.v[2][0]), "+a"(L.v[2][1]),
-                     "+a"(L.v[3][0]), "+a"(L.v[3][1]), "+a"(L.v[4][0]), "+a"(L.v[4][1]), "+a"(L.v[5][0]), "+a"(L.v[5][1]), "+a"(L.v[6][0]),
-                     "+a"(L.v[6][1]), "+a"(L.v[7][0]), "+a"(L.v[7][1]), "+a"(L.v[8][0]), "+a"(L.v[8][1]) : : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" : "+a"(L.v[0][0]), "+a"(L.v[0][1]), "+a"(L.v[0][2]), "+a"(L.v[1][0]), "+a"(L.v[1][1]), "+a"(L.v[1][2]),
-                     "+a"(L.v[2][0]), "+a"(L.v[2][1]), "+a"(L.v[2][2]), "+a"(L.v[3][0]), "+a"(L.v[3][1]), "+a"(L.v[3][2]), "+a"(L.v[4][0]),
-                     "+a"(L.v[4][1]), "+a"(L.v[4][2]), "+a"(L.v[5][0]), "+a"(L.v[5][1]), "+a"(L.v[5][2]), "+a"(L.v[6][0]), "+a"(L.v[6][1]),
-                     "+a"(L.v[6][2]), "+a"(L.v[7][0]), "+a"(L.v[7][1]), "+a"(L.v[7][2]), "+a"(L.v[8][0]), "+a"(L.v[8][1]), "+a"(L.v[8][2]) : : "memory");
-}
-// the landing zone (complete: wv_land_wait) moves into a register set
-template <int PX>
-__device__ __forceinline__ void wv_land_copy(const WvLand<PX>& L, WvSet<PX / 2>& C)
-{
-    constexpr int NV = WvPark<PX>::NV;
-    f2* dst[9] = {C.u1, C.u2, C.wx, C.wy, C.r, C.p11, C.p12, C.p21, C.p22};
-#pragma unroll
-    for (int p = 0; p < 9; ++p) {
-        if constexpr (PX % 4 == 0) {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) { dst[p][2 * q] = mk2(L.v[p][q].x, L.v[p][q].y); dst[p][2 * q + 1] = mk2(L.v[p][q].z, L.v[p][q].w); }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) dst[p][q] = mk2(L.v[p][q].x, L.v[p][q].y);
-        }
-    }
-}
+// NEXT row: global_load writes accumulation registers directly, nothing waits for them while the current row is worked on, and
+// when the row's turn comes they move to a register set (v_accvgpr_read, one per value).  The three functions are generated
+// (teeflow_land_gen.hip.h, tools/gen_land_regs.py -- its header says why the registers are fixed and hidden from hipcc):
+//   wv_land_issue<PX>(k, g, y)   the 9 planes of row y -> landing zone; nothing is waited for
+//   wv_land_wait<PX>()           s_waitcnt vmcnt(0).  MEASURED ON gfx950: a wave's stores can retire before OLDER loads of the same wave
+//                                have returned, so "vmcnt(<stores issued since>)" does NOT mean the loads are there (results differed on
+//                                full-size batches).  Hence vmcnt(0), placed BEFORE the step's stores go out: all that is outstanding then
+//                                is the landing zone itself and the previous step's stores, which have had a whole step to complete.
+//   wv_land_copy<PX>(C)          landing zone -> register set C (after wv_land_wait)
+template <int PX> __device__ __forceinline__ void wv_land_issue(const WvRows& k, const WvPlanes& g, int y);
+template <int PX> __device__ __forceinline__ void wv_land_wait();
+template <int PX> __device__ __forceinline__ void wv_land_copy(WvSet<PX / 2>& C);
+// Two zones (the three-iteration kernel keeps rows y+1 AND y+2 in flight; a row's zone is its parity):
+//   wv_land2_issue<PX, Z>(k, g, y)   row y -> zone Z
+//   wv_land2_wait_older<PX>()        s_waitcnt vmcnt(<loads per row>): everything but the NEWEST row's loads has arrived.  Sound although
+//                                    stores retire out of order: loads return in order among themselves, so an outstanding load of the
+//                                    older row would imply that all loads of the newer row are outstanding too -- more than the count allows.
+//                                    Only valid right after a newer row has been issued; otherwise wv_land_wait<PX>() (vmcnt(0)).
+//   wv_land2_copy<PX, Z>(C)          zone Z -> register set C
+template <int PX, int Z> __device__ __forceinline__ void wv_land2_issue(const WvRows& k, const WvPlanes& g, int y);
+template <int PX> __device__ __forceinline__ void wv_land2_wait_older();
+template <int PX, int Z> __device__ __forceinline__ void wv_land2_copy(WvSet<PX / 2>& C);
+#include "teeflow_land_gen.hip.h"
 
 // One row step in the INTERIOR of a strip: every stage runs on a row that exists and is neither the image's first nor its last
 // (y0 + 2 <= y <= min(yout_hi, s1_hi)), so there is no predicate left.  C takes row y, A holds row y-1 after its first primal
@@ -249,10 +204,10 @@ __device__ __forceinline__ void wv_land_copy(const WvLand<PX>& L, WvSet<PX / 2>&
 // done with them after stage 2) at the end of the step: one wave per SIMD hides its own load latency and needs half as many strips.
 template <int PX, bool PREFETCH>
 __device__ __forceinline__ void wv_step_full(const WvRows& k, const WvPlanes& g, int y, const unsigned* inw, WvSet<PX / 2>& C, WvSet<PX / 2>& A,
-                                             WvLand<PX>& land, WvPark<PX>& park, double& accA, double& accB)
+                                             WvPark<PX>& park, double& accA, double& accB)
 {
     constexpr int PP = PX / 2;
-    if constexpr (PREFETCH) wv_land_issue<PX>(k, g, y + 1, land);
+    if constexpr (PREFETCH) wv_land_issue<PX>(k, g, y + 1);
     else wv_issue<PX>(k, g, y, C);
     // row y-1's warp constants come back from the park (slots 6..8), row y's take their place after stage 1: between its two primal
     // updates a row's constants do not occupy registers
@@ -280,7 +235,7 @@ __device__ __forceinline__ void wv_step_full(const WvRows& k, const WvPlanes& g,
         f2 bu1[PP], bu2[PP], b11[PP], b21[PP], r11[PP], r12[PP], r21[PP], r22[PP];
         wv_unpark<PX>(park, 0, k.lane, bu1); wv_unpark<PX>(park, 1, k.lane, bu2); wv_unpark<PX>(park, 2, k.lane, b11); wv_unpark<PX>(park, 4, k.lane, b21);
         wv_dual_row<PP, false>(k.taut, bu1, bu2, m1, m2, b11, b12, b21, b22, inw, ~0u, r11, r12, r21, r22);
-        if constexpr (PREFETCH) wv_land_wait<PX>(land);             // before this step's stores go out (see wv_land_wait)
+        if constexpr (PREFETCH) wv_land_wait<PX>();             // before this step's stores go out (see wv_land_wait)
         const unsigned prow = (unsigned)((y - 2) * k.pitch + k.x);
         wv_st<PX>(g.ou1, prow, bu1); wv_st<PX>(g.ou2, prow, bu2);
         wv_st<PX>(g.o11, prow, r11); wv_st<PX>(g.o12, prow, r12); wv_st<PX>(g.o21, prow, r21); wv_st<PX>(g.o22, prow, r22);
@@ -288,7 +243,7 @@ __device__ __forceinline__ void wv_step_full(const WvRows& k, const WvPlanes& g,
     // row y-1 moves to the park
     wv_park<PX>(park, 0, k.lane, m1); wv_park<PX>(park, 1, k.lane, m2);
     wv_park<PX>(park, 2, k.lane, q11); wv_park<PX>(park, 3, k.lane, q12); wv_park<PX>(park, 4, k.lane, q21); wv_park<PX>(park, 5, k.lane, q22);
-    if constexpr (PREFETCH) wv_land_copy<PX>(land, A);          // row y+1 moves into the registers row y-1 has just left
+    if constexpr (PREFETCH) wv_land_copy<PX>(A);          // row y+1 moves into the registers row y-1 has just left
 }
 
 // One row step anywhere (the first and last rows of a strip, REPLAY strips): every stage under its row predicate; C moves to A by
@@ -425,23 +380,22 @@ __device__ __forceinline__ void iter2_wave_rows(const WvGeom& kg, WvPark<PX>& pa
         for (; y <= y_end && y < full_lo; ++y) wv_step_any<PX>(k, g, y, inw, S0, S1, park, accA, accB);
         int fold = 0;
         bool c_loaded = false;
-        WvLand<PX> land;
         if constexpr (PF) {
             // one wave per SIMD: the loads of row y+1 are in flight while row y is worked on (needs y+1 <= s1_hi)
             const int pf_hi = full_hi < k.s1_hi - 1 ? full_hi : k.s1_hi - 1;
             if (y + 1 <= pf_hi) {
                 wv_issue<PX>(k, g, y, S0);
                 for (; y + 1 <= pf_hi; y += 2) {
-                    wv_step_full<PX, true>(k, g, y, inw, S0, S1, land, park, accA, accB);
-                    wv_step_full<PX, true>(k, g, y + 1, inw, S1, S0, land, park, accA, accB);
+                    wv_step_full<PX, true>(k, g, y, inw, S0, S1, park, accA, accB);
+                    wv_step_full<PX, true>(k, g, y + 1, inw, S1, S0, park, accA, accB);
                     if (++fold == 60) { qA += (u64)accA; qB += (u64)accB; accA = accB = 0.0; fold = 0; }   // keep the double sums exact (< 2^53)
                 }
                 c_loaded = true;         // row y sits in S0
             }
         } else {
             for (; y + 1 <= full_hi; y += 2) {
-                wv_step_full<PX, false>(k, g, y, inw, S0, S1, land, park, accA, accB);
-                wv_step_full<PX, false>(k, g, y + 1, inw, S1, S0, land, park, accA, accB);
+                wv_step_full<PX, false>(k, g, y, inw, S0, S1, park, accA, accB);
+                wv_step_full<PX, false>(k, g, y + 1, inw, S1, S0, park, accA, accB);
                 if (++fold == 60) { qA += (u64)accA; qB += (u64)accB; accA = accB = 0.0; fold = 0; }
             }
         }

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--tuning", default="")
+    ap.add_argument("--k", type=int, default=2, help="iterations per launch of the form under test (3 for iter_variant=6)")
+    ap.add_argument("--lanes", type=int, default=1)
     a = ap.parse_args()
     import torch
     import tee_optical_flow_amd as T
@@ -28,7 +30,7 @@ def main():
     frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)
     flow = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
     eng = T.DenseFlow(max_batch=B)
-    eng.set_tuning("lanes", 1)
+    eng.set_tuning("lanes", a.lanes)
     for kv in filter(None, a.tuning.split(",")):
         k, v = kv.split("=")
         eng.set_tuning(k, int(v))
@@ -55,7 +57,7 @@ def main():
         px.append(hh * ww)
         hh, ww = int(round(hh * 0.8)), int(round(ww * 0.8))
     active = np.array([(inner[:, nl - 1 - l if False else l, w] > i).sum() for l, w, i in zip(lv, wp, it)])
-    act2 = np.array([np.minimum(np.maximum(inner[:, l, w] - i, 0), 2).sum() for l, w, i in zip(lv, wp, it)])   # pair-iterations
+    act2 = np.array([np.minimum(np.maximum(inner[:, l, w] - i, 0), a.k).sum() for l, w, i in zip(lv, wp, it)])   # pair-iterations
     work = act2 * np.array([px[l] for l in lv], dtype=np.float64)                  # px-iterations in the launch
     print(f"B={B} {H}x{W}: {n} launches, {ms.sum():.1f} ms in tvl1_iter, device total {st['ms_device']:.1f} ms")
     full = work / ms

@@ -47,6 +47,16 @@ def main():
     print(f"mean wave-slot occupancy over the launch: {busy:.3f}   (sum of wave lifetimes / (waves x span))")
     idle_tail = (en.max() - en).mean()
     print(f"mean idle tail per wave {idle_tail:.1f} us = {idle_tail / en.max():.3f} of the launch")
+    if hasattr(L, "tf_dbg_step_times"):
+        st2 = np.zeros((2, 96), np.uint64)
+        L.tf_dbg_step_times.argtypes = [C.c_void_p]
+        if L.tf_dbg_step_times(st2.ctypes.data_as(C.c_void_p)) == 0:
+            for w in range(2):
+                tt = st2[w].astype(np.int64)
+                tt = tt[tt > 0]
+                if len(tt) > 2:
+                    d = np.diff(tt) / 100.0
+                    print(f"wave {w}: {len(d)} row steps (us): " + " ".join(f"{x:.1f}" for x in d))
     e.close()
 
 
