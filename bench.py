@@ -511,6 +511,13 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                     nst = rec["dispatches"] / lps if lps else 0.0
                     whole = abs(nst - round(nst)) < 0.02 and round(nst) >= 1
                     wi = rec["totals_all_dispatches"]["SQ_INSTS_VALU"]
+                    # the vector-ALU roof: lane-instructions per second against CUs x 4 SIMDs x 16 lanes x clock
+                    peak = SIMDS * 16 * a.clock_ghz * 1e9
+                    t_all = round(nst) * lps * secs if whole and secs else None
+                    valu.update({"peak_lane_instructions_per_s": peak, "clock_ghz_assumed": a.clock_ghz,
+                                 "frac_executed": (wi * 64.0 / t_all / peak) if t_all else None,
+                                 "frac_useful": (rate * 40.0 / peak) if rate else None,
+                                 "frac_note": "executed = SQ_INSTS_VALU x 64 lanes / launch time; useful = 40 instructions per pixel-sweep x pixel-sweeps / launch time"})
                     valu.update({"source": f"profiles/{os.path.basename(f)}", "valu_wave_instructions_all_dispatches": wi,
                                  "dispatches_in_the_counter_pass": rec["dispatches"], "steps_in_the_counter_pass": nst,
                                  "valu_lane_instructions_per_px_sweep": (wi * 64.0 / (round(nst) * lps * units_per_launch)) if whole and units_per_launch else None,
@@ -519,6 +526,11 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                                  "simd_cycles_per_valu_inst_all_launches": rec.get("derived", {}).get("simd_cycles_per_valu_inst_all_launches")})
                     break
             roof["valu"] = valu
+            # the classifier's word: HBM is this launch's bound only if it runs near the streaming ceiling
+            if limiter and not limiter.startswith("hbm"):
+                roof["bound"] = "valu"
+                roof["bound_note"] = ("set from the counter-derived limiter: the launch keeps its system in registers for 25 sweeps (~35 flop per compulsory byte), "
+                                      "HBM traffic is far from the roof; the hbm figures above stay for the record, roofline.valu holds the fractions of the vector-ALU roof")
         if algo == "TVL1":
             # algorithmic (compulsory) bytes of the kernel that is actually launched: 9 plane reads + 6 writes once per TWO iterations
             roof["algorithmic_GBps_30B"] = rate * 30.0 / 1e9 if rate else None
@@ -559,7 +571,9 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             # data-independent rate of the whole job: executed pixel-iterations (pixel-sweeps) per second of the timed region
             ("px_iterations_per_s" if algo == "TVL1" else "px_sweeps_per_s"): world * acc["timed_iter_bytes"] / unit_bytes / dt,
             "roofline": roof,
-            "whole_solve_algorithmic_GBps": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
+            # NOT a bandwidth: the bytes a one-HBM-pass-per-iteration (per-sweep) formulation would move, over the device time.  The shipped
+            # kernels make one pass per two iterations / per 25 sweeps, so this exceeds their traffic (and may exceed the HBM peak).
+            "notional_whole_solve_GBps_one_pass_per_iteration": acc["total_bytes"] / 1e9 / (acc["ms_device"] / 1e3) if acc["ms_device"] else None,
         }
         if not a.no_profile and algo == "TVL1":
             # where a step's device time goes, from the library's own event pairs (instrumented single-lane repeats)

@@ -87,9 +87,9 @@ typedef struct tf_stats {
     double total_bytes;                    /* algorithmic bytes of the whole solve */
     unsigned long long inner_iters_total;  /* sum over pairs/levels/warps of executed inner iterations */
     unsigned long long outer_iters_total;  /* ... of executed outer iterations (= median passes) */
-    /* summed launch durations per stage of the solve, filled like iter_ms only under tf_set_profile(h,1), single lane.
-     * Lock-step driver: ms_warp (k_warp) and ms_median (k_median2) separately.  Scheduler driver: the warp / median /
-     * upsample / output tiles of all pairs share one kernel per super-step (ms_misc) and ms_sched is the state machine. */
+    /* summed launch durations per stage of the solve, filled like iter_ms only under tf_set_profile(h,1), single lane:
+     * ms_warp (k_warp_lds) and ms_median (k_median2).  ms_misc and ms_sched are always 0 (they belonged to the free-running
+     * scheduler driver removed in round 3; the fields stay so that ABI 2's struct layout does not change). */
     double ms_warp, ms_median, ms_misc, ms_sched;
 } tf_stats;
 
@@ -239,9 +239,7 @@ int tf_wase_compensate(tf_handle* h, float* flows, int n_flows, const uint8_t* b
 int tf_wase_compensate_device(tf_handle* h, float* flows, int n_flows, const uint8_t* bkgd, int n_frames, int H, int W, float scale,
                               float* background_out);
 /* per-launch record of the last solve run with tf_set_profile(h, 1): tvl1_iter launches in issue order (single lane);
- * returns the number of records, fills at most max_n.  Lock-step driver: (level, warp, first iteration) of the launch.
- * Scheduler driver (pairs of every level mixed in one launch): level = -1, warp = thousands of pixel-iterations the
- * launch executed, it = super-step index. */
+ * returns the number of records, fills at most max_n: (level, warp, first iteration) of each launch and its duration. */
 int tf_dbg_launch_profile(tf_handle* h, int* level, int* warp, int* it, float* ms, int max_n);
 /* strip sizing rule of the tvl1_iter kernel (host arithmetic only): rows per strip R (multiple of RY) and strip count S
  * for n_active pairs still iterating on a device with `slots` resident blocks */

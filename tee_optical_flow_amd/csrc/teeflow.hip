@@ -144,9 +144,14 @@ struct tf_handle {
     int sor_coop_small = 1;      // few pairs: co-resident 128 x 32 regions (0: the tiled form, as before)
     int sor_coop_s = 5;          // sweeps between two exchanges of (du, dv) in that kernel (the halo is 2 x this)
     int coop_share = 0;          // CUs (= resident 1024-thread blocks) this handle may fill with such a launch; set per call (calc_entry)
-    bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form from then on
+    bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form until the back-off has run out
+    int coop_backoff = 0;        // tiled solves (sub-batches) to sit out before the co-resident form is tried again; doubles with every abort
+    int coop_cooldown = 0;       // ... of which this many are left
+    int coop_rearms = 0;         // times the form was re-armed after a back-off
+    int coop_occ16 = -1, coop_occ8 = -1;   // resident blocks per CU of k_df_sor_rt_coop<4,16> / <4,8> (hipOccupancyMaxActiveBlocksPerMultiprocessor), -1 = not asked yet
     bool coop_used = false;      // this call launched k_df_sor_rt_coop
     int coop_aborts = 0;
+    int coop_test_occ16 = -1, coop_test_occ8 = -1;   // tests: pretend the occupancy query answered this
     int coop_test_mute = 0;      // tests: block 0 of every co-resident launch never raises its flag -> its neighbours give up -> the call is repeated tiled
     long long coop_launches = 0;
     unsigned coop_epoch = 0;     // flag value base of the next launch
@@ -785,6 +790,23 @@ int df_validate(tf_handle* h, const tf_deepflow_params& p)
     return TF_OK;
 }
 
+// one sub-batch solved: a handle that is sitting out an abort comes one step closer to trying the co-resident form again
+void coop_tick(tf_handle* h)
+{
+    if (h->coop_disabled && h->coop_cooldown > 0 && --h->coop_cooldown == 0) { h->coop_disabled = false; ++h->coop_rearms; }
+}
+// The co-resident form counts on ONE 1024-thread block (128 x 64 regions) or TWO 512-thread blocks (128 x 32) per CU.  Ask the runtime
+// instead of assuming it: a build whose register or LDS use has grown past that is refused the form (the tiled one does the same work).
+void coop_query_occupancy(tf_handle* h)
+{
+    if (h->coop_occ16 >= 0) return;
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_df_sor_rt_coop<4, 16>, 1024, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_df_sor_rt_coop<4, 8>, 512, 0) != hipSuccess) b = 0;
+    (void)hipGetLastError();
+    h->coop_occ16 = h->coop_test_occ16 >= 0 ? h->coop_test_occ16 : a;
+    h->coop_occ8 = h->coop_test_occ8 >= 0 ? h->coop_test_occ8 : b;
+}
 // k_df_sor_rt_coop's meeting place: a flag line per block that can be resident (one per CU) + the abort word behind them
 int coop_ensure(tf_handle* h)
 {
@@ -793,6 +815,7 @@ int coop_ensure(tf_handle* h)
     HIPC(h, hipMalloc(&h->coop_flags, ((size_t)h->coop_flag_lines + 1) * 128));
     HIPC(h, hipMemsetAsync(h->coop_flags, 0, ((size_t)h->coop_flag_lines + 1) * 128, h->stream));
     h->coop_epoch = 0;
+    coop_query_occupancy(h);
     return TF_OK;
 }
 // after the stream has drained: did a launch of this call give up waiting?  Then the results are void: the tiled form from now on.
@@ -804,8 +827,13 @@ int coop_aborted(tf_handle* h, bool* aborted)
     unsigned word = 0;
     HIPC(h, hipMemcpy(&word, h->coop_flags + (size_t)h->coop_flag_lines * 32, sizeof word, hipMemcpyDeviceToHost));
     if (!word) return TF_OK;
+    // Back-off, not a verdict: whatever held the CUs (another process, another stream) is usually gone a few solves later.  Sit out
+    // 16 tiled sub-batches, twice as many after every further abort (capped), then try the form again (coop_tick).
     h->coop_disabled = true;
     ++h->coop_aborts;
+    h->coop_backoff = h->coop_backoff ? (h->coop_backoff < 4096 ? 2 * h->coop_backoff : 4096) : 16;
+    h->coop_cooldown = h->coop_backoff;
+    h->err = "co-resident SOR launch gave up waiting (foreign work on the GPU?): sub-batch repeated with the tiled form";   // readable through tf_last_error
     HIPC(h, hipMemset(h->coop_flags, 0, ((size_t)h->coop_flag_lines + 1) * 128));
     *aborted = true;
     return TF_OK;
@@ -919,6 +947,7 @@ int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, in
     const int hl = 2 * S;
     *rows_ = 64;
     if (!h->sor_coop || h->coop_disabled || !h->coop_flags || h->sor_rt_shape != 3 || 64 - 2 * hl < 8 || 3 * hl > 64) return 0;
+    if (h->coop_occ16 < 1) return 0;                        // the runtime does not promise a resident 1024-thread block per CU: no co-resident form
     const int nx = g.w <= 128 ? 1 : 1 + (g.w - 128 + (128 - 2 * hl) - 1) / (128 - 2 * hl);
     const int ny = g.h <= 64 ? 1 : 1 + (g.h - 64 + (64 - 2 * hl) - 1) / (64 - 2 * hl);
     const int share = h->coop_share < h->coop_flag_lines / 2 ? h->coop_share : h->coop_flag_lines / 2;
@@ -930,6 +959,7 @@ int sor_coop_pairs(const tf_handle* h, const Geom& g, int B, int S, int* nx_, in
     // the 64-row regions satisfy 3 hl <= 64 for every S the knob allows)
     if (h->sor_coop != 2 && 32 - 2 * hl >= 8 && 3 * hl <= 32 && nx * ny * B < h->num_cus && nx * ny32 * B <= 2 * h->num_cus) {
         if (h->sor_coop != 3 && !h->sor_coop_small) return 0;
+        if (h->coop_occ8 < 2) return 0;                     // two resident 512-thread blocks per CU are what this form counts on
         if (nx * ny32 < 2 || nx * ny32 * B > 2 * share) return 0;
         *nx_ = nx; *ny_ = ny32; *rows_ = 32;
         return B;                                                       // all of them in one launch
@@ -1117,6 +1147,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         if (rc) return rc;
     }
     int kb = 0;
+    bool repeating = false;
     for (int c0 = 0; c0 < n_pairs; c0 += step, ++kb) {
         const int nb = n_pairs - c0 < step ? n_pairs - c0 : step;
         const uint8_t* dfr; int F, off0, off1;
@@ -1140,6 +1171,10 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         dfl = device ? flow_out + (size_t)c0 * npx * 2 : h->st_flow + (overlap ? (size_t)(kb & 1) * flow_half : 0);
         if (overlap && kb >= 2) HIPC(h, hipStreamWaitEvent(h->stream, h->cev[2 + (kb & 1)], 0));   // that half's last copy-out
         HIPC(h, hipEventRecord(h->ev[1], h->stream));
+        // what a repeat of this sub-batch must not count twice (an aborted co-resident attempt is void)
+        const unsigned long long snap_launches = h->iter_launches;
+        const double snap_bytes = h->df_sor_bytes, snap_px = h->df_sor_px;
+        const size_t snap_prof = h->prof_used;
         rc = deep ? df_solve_resident(h, dfr, F, nb, off0, off1, scale, dfl)
                   : solve_resident(h, dfr, F, nb, off0, off1, scale, dfl);
         if (rc) return rc;
@@ -1162,9 +1197,13 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
             if (rc) return rc;
             if (aborted) {                                       // solve this sub-batch again, tiled (what was copied out is overwritten)
                 if (overlap) HIPC(h, hipStreamSynchronize(h->copy_stream));
+                h->iter_launches = snap_launches; h->df_sor_bytes = snap_bytes; h->df_sor_px = snap_px; h->prof_used = snap_prof;
                 c0 -= step; --kb;
+                repeating = true;
                 continue;
             }
+            if (!repeating) coop_tick(h);                        // the repeat of an aborted sub-batch does not count towards the back-off
+            repeating = false;
         }
         float t;
         HIPC(h, hipEventElapsedTime(&t, h->ev[0], h->ev[1])); ms_h2d += t;
@@ -1241,7 +1280,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; t->coop_share = (claim.ok ? h->num_cus : 0) / L;
+        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; if (t->coop_test_occ16 != h->coop_test_occ16 || t->coop_test_occ8 != h->coop_test_occ8) { t->coop_test_occ16 = h->coop_test_occ16; t->coop_test_occ8 = h->coop_test_occ8; t->coop_occ16 = -1; coop_query_occupancy(t); } t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
         t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf; t->iter_k3 = h->iter_k3;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
@@ -1518,11 +1557,17 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (n == "sor_fuse") h->sor_fuse = value;
-    else if (n == "sor_coop") { h->sor_coop = value; if (value) { h->coop_disabled = false; for (auto* t : h->twins) t->coop_disabled = false; } }
+    else if (n == "sor_coop") {                       // setting the knob re-arms the form at once and forgets the back-off
+        h->sor_coop = value;
+        if (value) { h->coop_disabled = false; h->coop_backoff = h->coop_cooldown = 0; for (auto* t : h->twins) { t->coop_disabled = false; t->coop_backoff = t->coop_cooldown = 0; } }
+    }
     else if (n == "sor_coop_s") h->sor_coop_s = value;
     else if (n == "sor_coop_small") h->sor_coop_small = value ? 1 : 0;
     else if (n == "sor_coop_min_util") h->sor_coop_min_util = value;
     else if (n == "coop_test_mute") h->coop_test_mute = value ? 1 : 0;
+    else if (n == "coop_test_occ16") { h->coop_test_occ16 = value; h->coop_occ16 = -1; if (h->coop_flags) coop_query_occupancy(h); }
+    else if (n == "coop_test_occ8") { h->coop_test_occ8 = value; h->coop_occ16 = -1; if (h->coop_flags) coop_query_occupancy(h); }
+    else if (n == "coop_backoff") { h->coop_backoff = value < 0 ? 0 : value; }        // tests: next abort sits out 2 x this (0: the default 16)
     else if (n == "df_fuse_ds") h->df_fuse_ds = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "warp_margin") h->warp_margin = value < 0 ? 0 : (value > 40 ? 40 : value);
     else return fail(h, TF_ERR_INVALID_ARG, "unknown tuning knob %s", name);
@@ -1553,6 +1598,10 @@ TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
     if (n == "coop_launches") { v = h->coop_launches; for (auto* t : h->twins) v += t->coop_launches; }
     else if (n == "coop_aborts") { v = h->coop_aborts; for (auto* t : h->twins) v += t->coop_aborts; }
     else if (n == "coop_disabled") { v = h->coop_disabled; for (auto* t : h->twins) v |= (long long)t->coop_disabled; }
+    else if (n == "coop_rearms") { v = h->coop_rearms; for (auto* t : h->twins) v += t->coop_rearms; }
+    else if (n == "coop_cooldown") { v = h->coop_cooldown; for (auto* t : h->twins) v = v > t->coop_cooldown ? v : t->coop_cooldown; }
+    else if (n == "coop_occ16") v = h->coop_occ16;
+    else if (n == "coop_occ8") v = h->coop_occ8;
     return v;
 }
 

@@ -167,7 +167,7 @@ class DenseFlow:
         _lib.check(self._L.tf_set_tuning(self._h, name.encode(), int(value)), self._h, "tf_set_tuning")
 
     def counter(self, name):
-        """Debug counters of the engine (tf_dbg_counter): coop_launches, coop_aborts, coop_disabled."""
+        """Debug counters of the engine (tf_dbg_counter): coop_launches, coop_aborts, coop_disabled, coop_rearms, coop_cooldown, coop_occ16, coop_occ8."""
         return int(self._L.tf_dbg_counter(self._h, name.encode()))
 
     def _finish(self, st):

@@ -281,60 +281,73 @@ def test_coresident_form_is_chosen_per_level_by_how_well_it_fills_the_cus(oracle
 
 
 @pytest.mark.parametrize("form", [2, 3])          # 128 x 64 regions / the small-batch form (128 x 32 regions, two blocks per CU)
-def test_coresident_launch_that_cannot_meet_gives_up_and_the_call_is_repeated_tiled(oracle, form):
+def test_coresident_launch_that_cannot_meet_gives_up_backs_off_and_re_arms(oracle, form):
     """Every wait in k_df_sor_rt_coop is bounded.  With block 0 muted (it never raises its flag) its neighbours poll ~0.1 s, raise the
-    launch's abort word and leave, every other block follows, the kernel ends; the host sees the word after the solve, switches the handle
-    to the tiled form and solves the batch again -- same flows as ever, and the next call does not try again."""
+    launch's abort word and leave, every other block follows, the kernel ends; the host sees the word after the solve and solves the
+    batch again with the tiled form -- same flows as ever.  The form is not dropped for good: the handle sits out a number of tiled solves
+    (16, doubled by every further abort; 2 here), then tries again; tf_last_error says what happened."""
     import tee_optical_flow_amd as T
     from tee_optical_flow_amd.synth import speckle_pairs
     I0s, I1s = speckle_pairs(range(40, 43), 150, 300)
     eng = T.DenseFlow(algo="deepflow", max_batch=3)
     try:
         eng.set_tuning("sor_coop", form)
+        eng.set_tuning("coop_backoff", 1)                  # the next abort sits out 2 solves instead of 16
         eng.set_tuning("coop_test_mute", 1)
         flows = eng.calc_pairs(I0s, I1s)
-        assert eng.counter("coop_aborts") == 1 and eng.counter("coop_disabled") == 1
+        assert eng.counter("coop_aborts") == 1 and eng.counter("coop_disabled") == 1 and eng.counter("coop_cooldown") == 2
         n = eng.counter("coop_launches")
         for b in range(3):
             assert np.array_equal(flows[b], oracle.deepflow_calc(I0s[b], I1s[b])), f"pair {b}"
-        flows2 = eng.calc_pairs(I0s, I1s)
-        assert eng.counter("coop_launches") == n and eng.counter("coop_aborts") == 1
-        assert np.array_equal(np.asarray(flows2), np.asarray(flows))
-        eng.set_tuning("coop_test_mute", 0)
-        eng.set_tuning("sor_coop", form)                   # setting the knob re-arms the form
-        flows3 = eng.calc_pairs(I0s, I1s)
+        eng.set_tuning("coop_test_mute", 0)                # the neighbour on the GPU has gone
+        flows2 = eng.calc_pairs(I0s, I1s)                  # sits out (tiled), 1 left
+        assert eng.counter("coop_launches") == n and eng.counter("coop_disabled") == 1 and eng.counter("coop_cooldown") == 1
+        flows3 = eng.calc_pairs(I0s, I1s)                  # sits out (tiled), re-armed at its end
+        assert eng.counter("coop_launches") == n and eng.counter("coop_disabled") == 0 and eng.counter("coop_rearms") == 1
+        flows4 = eng.calc_pairs(I0s, I1s)                  # co-resident again
         assert eng.counter("coop_launches") > n and eng.counter("coop_aborts") == 1
-        assert np.array_equal(np.asarray(flows3), np.asarray(flows))
+        for f in (flows2, flows3, flows4):
+            assert np.array_equal(np.asarray(f), np.asarray(flows))
+        # a second abort doubles the wait; setting the knob re-arms at once
+        eng.set_tuning("coop_test_mute", 1)
+        eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_aborts") == 2 and eng.counter("coop_cooldown") == 4
+        eng.set_tuning("coop_test_mute", 0)
+        eng.set_tuning("sor_coop", form)
+        n2 = eng.counter("coop_launches")
+        flows5 = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") > n2 and eng.counter("coop_disabled") == 0
+        assert np.array_equal(np.asarray(flows5), np.asarray(flows))
     finally:
         eng.close()
 
 
-def test_deepflow_identical_frames_zero_and_errors(deep):
+def test_coresident_form_is_sized_from_the_occupancy_query(oracle):
+    """tf_create_deepflow's buffers come with a hipOccupancyMaxActiveBlocksPerMultiprocessor query for both co-resident instantiations: one
+    1024-thread block per CU (128 x 64 regions) and two 512-thread blocks (128 x 32) are what the form counts on.  A runtime that promises
+    less gets the tiled form (same bits)."""
     import tee_optical_flow_amd as T
-    from tee_optical_flow_amd.synth import speckle_pair
-    I0, _, _ = speckle_pair(3, 80, 80)
-    assert np.all(deep.calc(I0, I0, None) == 0.0)
-    with pytest.raises(T.OpticalFlowCalculationError):
-        deep.setLambda(0.1)                              # cv2's DeepFlow object has no setters either
-    with pytest.raises(T.OpticalFlowCalculationError):
-        T.DenseFlow(algo="farneback")
-    m = __import__("tee_optical_flow_amd.pipeline", fromlist=["make_flow_model"]).make_flow_model("deepflow")
-    assert m.algo == "deepflow"
-    m.close()
-
-
-def test_deepflow_sector_masked_frames(deep, oracle):
-    """Echo frames are exactly black outside the ultrasound sector: there the data term vanishes (Ix = Iy = Iz = 0: a11 = a22 = zeta^2 + the
-    smoothness weights, b = the smoothness contributions alone) and the flow is filled in from the sector's edge -- diagonals and right-hand
-    sides orders of magnitude away from the textured case, through the same pre-scaled division."""
-    from tee_optical_flow_amd.synth import speckle_sequence
-    H, W = 200, 264
-    yy, xx = np.mgrid[0:H, 0:W]
-    ang = np.arctan2(xx - W / 2, yy + H * 0.05)
-    sector = (np.abs(ang) < 0.7) & (np.hypot(xx - W / 2, yy + H * 0.05) < H * 0.98)
-    fr = np.where(sector[None], speckle_sequence(77, 3, H, W), 0).astype(np.uint8)
-    flows = deep.calc_batch(fr)
-    for i in range(2):
-        ref = oracle.deepflow_calc(fr[i], fr[i + 1])
-        assert np.array_equal(np.asarray(flows[i]).view(np.uint32), ref.view(np.uint32)) or np.array_equal(flows[i], ref), f"pair {i}"
-        assert np.isfinite(ref).all()
+    from tee_optical_flow_amd.synth import speckle_pairs
+    I0s, I1s = speckle_pairs(range(50, 53), 150, 300)
+    eng = T.DenseFlow(algo="deepflow", max_batch=3)
+    try:
+        eng.set_tuning("sor_coop", 2)
+        ref = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_occ16") >= 1 and eng.counter("coop_occ8") >= 2, "this build no longer fits the co-resident form's block shapes"
+        n = eng.counter("coop_launches")
+        assert n > 0
+        eng.set_tuning("coop_test_occ16", 0)               # as if a 1024-thread block did not fit a CU
+        out = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") == n and eng.counter("coop_aborts") == 0
+        assert np.array_equal(np.asarray(out), np.asarray(ref))
+        eng.set_tuning("coop_test_occ16", -1)
+        eng.set_tuning("sor_coop", 3)                      # the small-batch form needs two blocks per CU
+        eng.set_tuning("coop_test_occ8", 1)
+        out = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") == n
+        eng.set_tuning("coop_test_occ8", -1)
+        out2 = eng.calc_pairs(I0s, I1s)
+        assert eng.counter("coop_launches") > n
+        assert np.array_equal(np.asarray(out), np.asarray(ref)) and np.array_equal(np.asarray(out2), np.asarray(ref))
+    finally:
+        eng.close()
