@@ -107,7 +107,6 @@ struct tf_handle {
     int iter_k3 = 0;             // 1: THREE iterations per launch (k_iter3_wave) wherever k_iter2_wave applies and inner_iterations is a multiple of 3
     int wave_pf = 0;             // k_iter2_wave: 1 = one wave per SIMD with the next row's loads in flight (three register sets), 0 = two or three waves per SIMD
     int wave_slots = 0;          // k_iter2_wave: resident waves to size the strips for (0 = what the occupancy query says)
-    int lds_pad_kb = 0;          // experiment: extra dynamic LDS per k_iter2_rows block (lowers the resident blocks per CU)
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
                                  // @512^2: 1 lane 2180, 2 lanes 2470, 3 lanes 2415, 4 lanes 2165 pairs/s (DeepFlow 377 vs 309)
@@ -131,10 +130,10 @@ struct tf_handle {
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
     int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
     int sor_plain_div = 0;       // tests: k_df_sor_rt takes its plain-IEEE-division path (what a block with out-of-range diagonals does)
-    int sor_rt_shape = 3;        // k_df_sor_rt: 0 = 8 bands x 8 rows (512 threads), 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
+    int sor_rt_shape = 3;        // k_df_sor_rt: 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
                                  // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
-    int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (2: four pixels per thread, 16-byte loads; 1: one pixel per
-                                 // thread; 0: k_df_data then k_df_smooth)
+    int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (non-zero: k_df_data_smooth4, four pixels per thread,
+                                 // 16-byte loads; 0: k_df_data then k_df_smooth, the plain form it is tested against)
     int sor_coop = 1;            // DeepFlow: all sweeps of a fixed-point iteration in one launch of co-resident regions (k_df_sor_rt_coop) where a
                                  // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form,
                                  // 2 = 128 x 64 regions whatever the batch size and however full the launches (tests), 3 = the small-batch form
@@ -400,7 +399,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     // short strips (latency of a few steps) instead of a few long ones
     strip_shape(h, g, active_hint > 0 && h->adaptive_strips ? active_hint : B, &R, &QX, &RY, &threads, true);
     const int LW = QX * 4 + 4;
-    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 2 * RY * QX) * sizeof(float) + (size_t)h->lds_pad_kb * 1024;
+    const size_t shmem = (size_t)(32 + 8 * RY * LW + 2 * (RY + 1) * LW + 2 * RY * QX) * sizeof(float);
     if (h->dynamic_strips && B <= 1024) {
         // strips sized on the device from the exact number of pairs still iterating; the grid covers the largest item count
         int slots = h->slots_override;
@@ -934,8 +933,7 @@ int launch_sor_rt(tf_handle* h, const DfBufs& d, const Geom& g, int B, float ome
     if (!whole && shape == 2 && 32 - 4 * n < 4) n = 6;                     // 128 x 32 regions: at most 6 sweeps per launch (core of 8 rows)
     if (n > left) n = left;
     const int hl = whole ? 0 : 2 * n;
-    if (shape == 0) launch_sor_rt_t<8, 8>(d, g, B, omega, n, hl, s, h->sor_plain_div);
-    else if (shape == 2) launch_sor_rt_t<4, 8>(d, g, B, omega, n, hl, s, h->sor_plain_div);
+    if (shape == 2) launch_sor_rt_t<4, 8>(d, g, B, omega, n, hl, s, h->sor_plain_div);
     else launch_sor_rt_t<4, 16>(d, g, B, omega, n, hl, s, h->sor_plain_div);
     return n;
 }
@@ -986,8 +984,7 @@ void df_refine_level(tf_handle* h, const float* pyr_l, int off0, int off1, const
     hipLaunchKernelGGL(k_df_grad2, gr, bl, 0, s, d, g);
     const int fuse = h->sor_fuse < 0 ? 0 : h->sor_fuse;
     for (int fp = 0; fp < h->DP.fixed_point_iterations; ++fp) {
-        if (h->df_fuse_ds == 2) hipLaunchKernelGGL(k_df_data_smooth4, dim3((g.w + 255) / 256, (g.h + 3) / 4, B), bl, 0, s, d, cur, g, c);
-        else if (h->df_fuse_ds) hipLaunchKernelGGL(k_df_data_smooth, gr, bl, 0, s, d, cur, g, c);
+        if (h->df_fuse_ds) hipLaunchKernelGGL(k_df_data_smooth4, dim3((g.w + 255) / 256, (g.h + 3) / 4, B), bl, 0, s, d, cur, g, c);
         else {
             hipLaunchKernelGGL(k_df_data, gr, bl, 0, s, d, cur, g, c);
             hipLaunchKernelGGL(k_df_smooth, gr, bl, 0, s, d, cur, g);
@@ -1281,7 +1278,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         tf_handle* t = h->twins[k - 1];
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
         t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; if (t->coop_test_occ16 != h->coop_test_occ16 || t->coop_test_occ8 != h->coop_test_occ8) { t->coop_test_occ16 = h->coop_test_occ16; t->coop_test_occ8 = h->coop_test_occ8; t->coop_occ16 = -1; coop_query_occupancy(t); } t->coop_share = (claim.ok ? h->num_cus : 0) / L;
-        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry; t->lds_pad_kb = h->lds_pad_kb;
+        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
         t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf; t->iter_k3 = h->iter_k3;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
@@ -1544,7 +1541,6 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "wave_px") h->wave_px = value;
     else if (n == "wave_slots") h->wave_slots = value;
     else if (n == "wave_pf") h->wave_pf = value ? 1 : 0;
-    else if (n == "lds_pad_kb") h->lds_pad_kb = value < 0 ? 0 : value;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;

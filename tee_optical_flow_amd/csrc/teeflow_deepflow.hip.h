@@ -175,77 +175,11 @@ __global__ __launch_bounds__(256) void k_df_smooth(DfBufs d, int cur, Geom g)
     d.A11[i] = a11; d.A22[i] = a22; d.b1[i] = b1; d.b2[i] = b2;
 }
 
-// k_df_data + k_df_smooth in one pass: the data term stays in registers, and the smoothness weights of the pixel's left and
-// upper neighbours are recomputed here (same expression on the same operands -> same bits) instead of being read back, so
-// A11 / A22 / b1 / b2 are written once and never re-read: 72 instead of 116 B/px per fixed-point iteration.
-__global__ __launch_bounds__(256) void k_df_data_smooth(DfBufs d, int cur, Geom g, DfConst c)
-{
-    DF_XY();
-    const size_t i = (size_t)b * g.splane + j;
-    const float Ix = d.Ix[i], Iy = d.Iy[i], Iz = d.Iz[i], Ixx = d.Ixx[i], Ixy = d.Ixy[i], Iyy = d.Iyy[i], Ixz = d.Ixz[i], Iyz = d.Iyz[i];
-    const float du = d.du[i], dv = d.dv[i];
-    float derivNorm = Ix * Ix + Iy * Iy + c.zeta2;
-    const float Ik1z = Iz + Ix * du + Iy * dv;
-    float weight = (c.delta2 / sqrtf(Ik1z * Ik1z / derivNorm + c.eps2)) / derivNorm;
-    float a11 = weight * (Ix * Ix) + c.zeta2;
-    float a12 = weight * (Ix * Iy);
-    float a22 = weight * (Iy * Iy) + c.zeta2;
-    float b1 = -weight * (Iz * Ix);
-    float b2 = -weight * (Iz * Iy);
-    derivNorm = Ixx * Ixx + Ixy * Ixy + c.zeta2;
-    const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + c.zeta2;
-    const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
-    const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-    weight = c.gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + c.eps2);
-    a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-    a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-    a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-    b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-    b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
-    // smoothness weights (forward differences of W + dW, 0 across the border) of this pixel, its left and its upper neighbour
-    const float* Wu = d.Wu[cur];
-    const float* Wv = d.Wv[cur];
-    const bool hl = x > 0, hr = x < W - 1, hu = y > 0, hd = y < H - 1;
-    const float wu = Wu[i], wv = Wv[i];
-    const float cu = wu + du, cv = wv + dv;
-    const float wuR = hr ? Wu[i + 1] : 0.f, wvR = hr ? Wv[i + 1] : 0.f, wuD = hd ? Wu[i + pitch] : 0.f, wvD = hd ? Wv[i + pitch] : 0.f;
-    const float wuL = hl ? Wu[i - 1] : 0.f, wvL = hl ? Wv[i - 1] : 0.f, wuU = hu ? Wu[i - pitch] : 0.f, wvU = hu ? Wv[i - pitch] : 0.f;
-    float wself, wleft = 0.f, wup = 0.f;
-    {
-        const float ux = hr ? (wuR + d.du[i + 1]) - cu : 0.f, vx = hr ? (wvR + d.dv[i + 1]) - cv : 0.f;
-        const float uy = hd ? (wuD + d.du[i + pitch]) - cu : 0.f, vy = hd ? (wvD + d.dv[i + pitch]) - cv : 0.f;
-        wself = c.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + c.eps2);
-    }
-    if (hl) {
-        const float cuL = wuL + d.du[i - 1], cvL = wvL + d.dv[i - 1];
-        const float ux = cu - cuL, vx = cv - cvL;                               // the left pixel always has a right neighbour: this one
-        const float uy = hd ? (Wu[i - 1 + pitch] + d.du[i - 1 + pitch]) - cuL : 0.f, vy = hd ? (Wv[i - 1 + pitch] + d.dv[i - 1 + pitch]) - cvL : 0.f;
-        wleft = c.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + c.eps2);
-    }
-    if (hu) {
-        const float cuU = wuU + d.du[i - pitch], cvU = wvU + d.dv[i - pitch];
-        const float ux = hr ? (Wu[i - pitch + 1] + d.du[i - pitch + 1]) - cuU : 0.f, vx = hr ? (Wv[i - pitch + 1] + d.dv[i - pitch + 1]) - cvU : 0.f;
-        const float uy = cu - cuU, vy = cv - cvU;                               // the upper pixel always has a lower neighbour: this one
-        wup = c.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + c.eps2);
-    }
-    // smoothness contributions in upstream's scatter order (k_df_smooth): red pass before black pass, horizontal before vertical
-    const bool red = ((x + y) & 1) == 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const bool own = red ? (k == 0) : (k == 1);
-        if (own) { if (hr) { b1 += wself * (wuR - wu); a11 += wself; b2 += wself * (wvR - wv); a22 += wself; } }
-        else if (hl) { b1 -= wleft * (wu - wuL); a11 += wleft; b2 -= wleft * (wv - wvL); a22 += wleft; }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const bool own = red ? (k == 0) : (k == 1);
-        if (own) { if (hd) { b1 += wself * (wuD - wu); a11 += wself; b2 += wself * (wvD - wv); a22 += wself; } }
-        else if (hu) { b1 -= wup * (wu - wuU); a11 += wup; b2 -= wup * (wv - wvU); a22 += wup; }
-    }
-    d.A11[i] = a11; d.A12[i] = a12; d.A22[i] = a22; d.b1[i] = b1; d.b2[i] = b2; d.wg[i] = wself;
-}
-
-// k_df_data_smooth with FOUR pixels per thread: every plane is read with 16-byte loads (the 4-byte loads of the one-pixel form
+// k_df_data + k_df_smooth in one pass, FOUR pixels per thread (k_df_data_smooth4): the data term stays in registers, and the smoothness
+// weights of a pixel's left and upper neighbours are recomputed (same expression on the same operands -> same bits) instead of being read
+// back, so A11 / A22 / b1 / b2 are written once and never re-read: 72 instead of 116 B/px per fixed-point iteration.  (The one-pixel-per-
+// thread form of the same fusion was removed in round 4; the two-kernel form above stays as the plain reference the fused one is tested against.)
+// Every plane is read with 16-byte loads (the 4-byte loads of the one-pixel form
 // reach 3.4 TB/s on its 72 B per pixel; this kernel is 14 % of a DeepFlow solve), the weight of a pixel's left neighbour is the
 // previous pixel's own weight (same expression on the same operands: computed once), only the quad's first pixel recomputes it.
 // Same operations in the same order per pixel -> bit-identical to k_df_data + k_df_smooth.

@@ -33,13 +33,13 @@ def test_blur_bit_exact(deep, oracle, shape):
     assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("fuse,shape_knob", [(0, 0), (1, 0), (2, 1), (3, 0), (3, 1), (4, 1), (5, 0), (5, 1), (6, 1), (7, 0), (8, 1),
+@pytest.mark.parametrize("fuse,shape_knob", [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1),
                                              (1, 2), (3, 2), (5, 2), (6, 2), (8, 2), (5, 3), (3, 3)])
 @pytest.mark.parametrize("shape,amp", [((64, 64), 1.0), ((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((70, 200), 2.0), ((96, 96), 3.0), ((150, 301), 2.0), ((333, 141), 1.0)])
 def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_knob):
     """One cv::VariationalRefinement::calcUV (warp, 8 derivative planes, 5 x [data term, smoothness, 25 red-black SOR sweeps]) in
     every SOR form: one colour per launch (fuse 0), n sweeps per launch of the register-tile kernel on 128 x 64 regions held by
-    8 bands x 8 rows (shape 0) or 16 bands x 4 rows (shape 1), on 128 x 32 regions held by 8 bands x 4 rows (shape 2), or the
+    16 bands x 4 rows (shape 1), on 128 x 32 regions held by 8 bands x 4 rows (shape 2), or the
     launcher's own choice between 1 and 2 (shape 3, the default); a level that fits one region runs all 25 sweeps in one launch."""
     from scipy import ndimage
     from tee_optical_flow_amd import _lib
@@ -65,7 +65,7 @@ def test_variational_refinement_bit_exact(deep, oracle, shape, amp, fuse, shape_
     assert np.array_equal(gv, rv)
 
 
-@pytest.mark.parametrize("shape_knob", [0, 1, 2])
+@pytest.mark.parametrize("shape_knob", [1, 2])
 def test_sor_plain_division_path_bit_exact(deep, oracle, shape_knob):
     """A block whose diagonals leave the range the pre-scaled division is exact for takes the plain IEEE division; real data never
     gets there, so the path is forced (sor_plain_div) -- both divisions are correctly rounded, the results must not move."""
@@ -147,7 +147,7 @@ def test_sor_two_bands_per_wave_bit_exact(deep, oracle, shape, plain):
     assert np.array_equal(gu, ru) and np.array_equal(gv, rv)
 
 
-@pytest.mark.parametrize("ds", [0, 1, 2])
+@pytest.mark.parametrize("ds", [0, 2])
 @pytest.mark.parametrize("shape,amp", [((97, 131), 4.0), ((40, 52), 40.0), ((26, 26), 0.5), ((150, 301), 2.0), ((333, 141), 1.0), ((65, 258), 3.0)])
 def test_data_and_smoothness_term_forms_bit_exact(deep, oracle, shape, amp, ds):
     """The linear system of a fixed-point iteration in its three kernel forms: k_df_data + k_df_smooth (0), both in one pass with one

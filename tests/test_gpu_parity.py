@@ -98,7 +98,7 @@ def test_non_default_parameters_match_oracle(oracle, params):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
 @pytest.mark.parametrize("params", [dict(), dict(inner_iterations=7, outer_iterations=4), dict(inner_iterations=4, outer_iterations=3, epsilon=0.002),
                                     dict(median_filtering=1, epsilon=0.03), dict(inner_iterations=9, outer_iterations=5, epsilon=0.004),
                                     dict(inner_iterations=3, outer_iterations=4, median_filtering=3)])
