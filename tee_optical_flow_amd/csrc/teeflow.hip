@@ -102,6 +102,7 @@ struct tf_handle {
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
     int iter_wave = 0;           // 1: batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
                                  // instead of k_iter2_rows; 0 = never
+    int wave_max_w = 512;        // widest level the one-wave-per-strip kernels take (<= 512)
     int wave_minrows = 8;        // k_iter2_wave: shortest strip (rows)
     int wave_px = 0;             // k_iter2_wave: pixels per lane (4 / 6 / 8); 0 = the narrowest form that covers the level's width
     int iter_k3 = 0;             // 1: THREE iterations per launch (k_iter3_wave) wherever k_iter2_wave applies and inner_iterations is a multiple of 3
@@ -366,7 +367,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
         hipLaunchKernelGGL(k_iter2_tile, dim3((g.w + T2_OW - 1) / T2_OW, (g.h + T2_OH - 1) / T2_OH, B), dim3(256), 0, s, A);
         return;
     }
-    if (h->iter_wave && g.w <= 512 && B <= 1024) {
+    if (h->iter_wave && g.w <= h->wave_max_w && B <= 1024) {
         // one wave per strip: PX pixels per lane (float4 / float2 loads need PX*lanes to stay inside the padded row)
         const int px = wave_px(h, g);
         const bool pf = h->wave_pf != 0;
@@ -429,7 +430,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
 // the median cadence stays on a pass boundary, the CPU variant's stop rule)
 bool three_ok(const tf_handle* h, const Geom& g, int B, int inner)
 {
-    return h->iter_k3 && h->iter_wave && h->iter_variant >= 2 && h->P.variant == TF_VARIANT_CPU && inner % 3 == 0 && g.w <= 512 && B <= 1024 && rows_ok(h, g, B);
+    return h->iter_k3 && h->iter_wave && h->iter_variant >= 2 && h->P.variant == TF_VARIANT_CPU && inner % 3 == 0 && g.w <= h->wave_max_w && B <= 1024 && rows_ok(h, g, B);
 }
 // launch one three-iteration pass (k_iter3_wave); the caller has checked three_ok()
 void launch_iter3(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
@@ -1279,7 +1280,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
         t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; if (t->coop_test_occ16 != h->coop_test_occ16 || t->coop_test_occ8 != h->coop_test_occ8) { t->coop_test_occ16 = h->coop_test_occ16; t->coop_test_occ8 = h->coop_test_occ8; t->coop_occ16 = -1; coop_query_occupancy(t); } t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
-        t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf; t->iter_k3 = h->iter_k3;
+        t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_max_w = h->wave_max_w; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf; t->iter_k3 = h->iter_k3;
         t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
         t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
         t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->sor_plain_div = h->sor_plain_div; t->tile_max_w = h->tile_max_w;
@@ -1539,6 +1540,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "iter_wave") h->iter_wave = value;
     else if (n == "wave_minrows") h->wave_minrows = value < 1 ? 1 : value;
     else if (n == "wave_px") h->wave_px = value;
+    else if (n == "wave_max_w") h->wave_max_w = value < 0 ? 0 : (value > 512 ? 512 : value);
     else if (n == "wave_slots") h->wave_slots = value;
     else if (n == "wave_pf") h->wave_pf = value ? 1 : 0;
     else if (n == "adaptive_strips") h->adaptive_strips = value;

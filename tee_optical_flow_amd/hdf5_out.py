@@ -54,7 +54,9 @@ def create_gzip9(f, name, data, min_parallel_bytes=1 << 20):
 
 
 def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config,
-                              mode, no_saliency, include_waveforms, save_mask_subset=None):
+                              mode, no_saliency, include_waveforms, save_mask_subset=None, *, echo=None, nframes=None):
+    """`echo` (float16 [N,H,W] = rgb2gray(nparr).astype(float16), reference :400-402) and `nframes` may be handed over instead of
+    `nparr` (process_folder's worker processes: the reader stage makes `echo`, the RGB frames need not travel to the writer)."""
     try:
         import h5py
     except ImportError as e:  # pragma: no cover
@@ -65,7 +67,7 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
     tmp_path = f"{save_path}.part{os.getpid()}"
     try:
         _write(h5py, tmp_path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config, mode, no_saliency,
-               include_waveforms, save_mask_subset)
+               include_waveforms, save_mask_subset, echo, nframes)
         os.replace(tmp_path, save_path)
     finally:
         if os.path.exists(tmp_path):
@@ -73,14 +75,14 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
 
 
 def _write(h5py, path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config, mode, no_saliency,
-           include_waveforms, save_mask_subset):
+           include_waveforms, save_mask_subset, echo=None, nframes=None):
     nan = float("nan")
     with h5py.File(path, "w") as f:
-        create_gzip9(f, "echo", rgb2gray(nparr).astype(np.float16))
+        create_gzip9(f, "echo", np.asarray(echo, dtype=np.float16) if echo is not None else rgb2gray(nparr).astype(np.float16))
         fd = create_gzip9(f, "flow", np.asarray(flow_arr).astype(np.float16))
         # missing metadata: same attribute names and float64 type as a complete study, value NaN (units_converted says so)
         fd.attrs["frame_rate"] = nan if metadata["frame_rate"] is None else metadata["frame_rate"]
-        fd.attrs["nframes"] = nparr.shape[0]
+        fd.attrs["nframes"] = int(nframes) if nframes is not None else nparr.shape[0]
         fd.attrs["pixel_spacing"] = nan if metadata["pixel_spacing"] is None else metadata["pixel_spacing"]
         fd.attrs["ID"] = patient_id
         fd.attrs["HR"] = heart_rate if heart_rate is not None else 0

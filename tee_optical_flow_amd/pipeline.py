@@ -245,11 +245,57 @@ def dicom_to_study(ds, arr, convert_color=None):
     return arr, extract_dicom_metadata(ds), str(getattr(ds, "PatientID", "")), int(getattr(ds, "HeartRate", 0) or 0)
 
 
+class StudyWorkers:
+    """Worker processes for process_folder's reader/mask and deflate/write stages, for callers that hold a flow model (or a segmentor on
+    the GPU) across many calls: create this object BEFORE anything in the process touches the GPU -- starting a process from a
+    GPU-initialised one is not safe on ROCm hosts -- and hand it to process_folder(workers=...).  process_folder(workers="process" /
+    "auto") makes its own for one call."""
+
+    def __init__(self, n_readers=2, n_writers=2):
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        ctx = mp.get_context("spawn")
+        self.n_readers, self.n_writers = max(1, n_readers), max(1, n_writers)
+        self.readers = ProcessPoolExecutor(self.n_readers, mp_context=ctx)
+        self.writers = ProcessPoolExecutor(self.n_writers, mp_context=ctx)
+        # make the pools start their processes now (they are created lazily on first submit)
+        for f in [self.readers.submit(os.getpid) for _ in range(self.n_readers)] + [self.writers.submit(os.getpid) for _ in range(self.n_writers)]:
+            f.result()
+
+    def close(self):
+        self.readers.shutdown(wait=True)
+        self.writers.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _prepare_study(reader, path, mode, flipLR, config, want_echo):
+    """Reader stage of process_folder (module level: it also runs in worker processes).  Reads the study and -- for the Otsu mode,
+    which is pure numpy/scipy -- computes its masks one study ahead of the GPU; with the solver at milliseconds per pair, this host
+    work and the gzip-9 write are what a study costs.  `want_echo`: also the `echo` dataset (rgb2gray of the frames as float16,
+    reference :400-402), so that the writer process does not need the RGB frames."""
+    nparr, md, pid, hr = reader(path)
+    masks_ahead = None
+    prepped = _prep_frames(nparr, flipLR)
+    if mode == "otsu":
+        from .masks import predict_movie_thres
+        masks_ahead = predict_movie_thres(prepped, verbose=False, config=config)
+    echo = None
+    if want_echo:
+        from .frames import rgb2gray
+        echo = rgb2gray(prepped).astype(np.float16)
+    return nparr, md, pid, hr, masks_ahead, echo
+
+
 def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, chunk_index=0, mode="RVIO_2class", bkgd_comp="none",
                    flipLR=False, verbose=True, recalculate=False, no_saliency=True, OF_algo="TVL1", save_mask_subset=None,
                    include_waveforms=False, waveform_folder=None, pixel_spacing=None, frame_rate=None, process_subset=False,
                    file_subset_list=(), *, rank=0, world=1, extensions=("dcm",), reader=read_study, flow_model=None, config=None,
-                   device_id=0):
+                   device_id=0, workers="auto", n_readers=2, n_writers=2):
     """Drop-in for the reference's process_folder (:243-290), same positional signature and the same rules:
       * the folder listing is cut into `nchunks` slices of len // nchunks files, this call takes slice `chunk_index`
         (the remainder files are dropped, as the reference does -- SURVEY.md Appendix C.8);
@@ -260,8 +306,13 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
       * like the reference, `pixel_spacing` / `frame_rate` are accepted and ignored, and `config` is not forwarded unless given.
     Beyond the reference: the slice is dealt round-robin over `world` ranks (one process per GPU, rank r takes files
     r, r+world, ...: no exchange is needed, studies are independent), one flow model serves all studies of the call, and
-    the walk is a three-stage pipeline: a reader thread loads study k+1 (and computes its Otsu masks), the caller's thread
-    solves study k on the GPU, a writer thread deflates/writes study k-1.  Returns the list of (filename, error string)."""
+    the walk is a three-stage pipeline: the reader stage loads study k+1 (and computes its Otsu masks and the `echo` dataset), the
+    caller's thread solves study k on the GPU, the writer stage deflates/writes study k-1.  `workers`: "process" runs the reader and
+    writer stages in `n_readers` + `n_writers` worker PROCESSES (spawned here, before this call's first GPU call; the mask stage and
+    the deflate both hold the interpreter lock, which is why threads bought 3 %), "thread" in one thread each, "auto" takes
+    processes when this call creates the flow model itself (no `flow_model`, no `segmentor_model`: nothing in the caller's hands has
+    initialised the GPU yet as far as this function can tell) and more than one study is to do.  Returns the list of
+    (filename, error string)."""
     os.makedirs(save_folder, exist_ok=True)
     file_list = sorted(os.listdir(dcm_folder))                      # os.listdir order is arbitrary; sorted = same slices on every rank
     errors = []
@@ -277,28 +328,44 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     mine = file_list[chunk_index * split:(chunk_index + 1) * split][rank::world]
     own = flow_model is None
     model = None
-    writer = ThreadPoolExecutor(1)
-    reader_pool = ThreadPoolExecutor(1)
     pending = []
+    cfg_masks = config if config is not None else default_optical_flow_config()
+    shared = workers if isinstance(workers, StudyWorkers) else None
+    if shared is not None:
+        n_readers, n_writers = shared.n_readers, shared.n_writers
+    use_proc = workers == "process" or (workers == "auto" and flow_model is None and segmentor_model is None)
+    state = {"writer": None, "reader_pool": None, "proc": False}
+    echo_of = {}
 
-    def prepare(filename):
-        """Read the study and -- for the Otsu mode, which is pure numpy/scipy -- compute its masks, one study ahead of the
-        GPU: with the solver at milliseconds per pair, this host work and the gzip-9 write are what a study costs."""
-        nparr, md, pid, hr = reader(os.path.join(dcm_folder, filename))
-        masks_ahead = None
-        if mode == "otsu":
-            from .masks import predict_movie_thres
-            masks_ahead = predict_movie_thres(_prep_frames(nparr, flipLR), verbose=False,
-                                              config=config if config is not None else default_optical_flow_config())
-        return nparr, md, pid, hr, masks_ahead
+    def start_pools(n_todo):
+        # worker processes only make sense for more than one study, and they must exist before the first GPU call of this function
+        if shared is not None:
+            state["reader_pool"], state["writer"], state["proc"] = shared.readers, shared.writers, True
+        elif use_proc and n_todo > 1:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            ctx = mp.get_context("spawn")
+            state["reader_pool"] = ProcessPoolExecutor(max(1, min(n_readers, n_todo)), mp_context=ctx)
+            state["writer"] = ProcessPoolExecutor(max(1, n_writers), mp_context=ctx)
+            state["proc"] = True
+        else:
+            state["reader_pool"] = ThreadPoolExecutor(1)
+            state["writer"] = ThreadPoolExecutor(1)
 
     def defer(job):
         from .hdf5_out import save_optical_flow_to_hdf5
-        pending.append((job[0], writer.submit(save_optical_flow_to_hdf5, *job)))
+        if state["proc"]:
+            # the writer process needs neither the RGB frames (the reader stage made `echo` from them) nor float32 flow (the file holds float16)
+            save_path, flow_arr, nparr, mask_dict, *rest = job
+            echo = echo_of.pop(save_path, None)
+            job = (save_path, np.asarray(flow_arr).astype(np.float16), None if echo is not None else nparr, mask_dict, *rest)
+            pending.append((save_path, state["writer"].submit(save_optical_flow_to_hdf5, *job, echo=echo, nframes=int(np.asarray(nparr).shape[0]))))
+        else:
+            pending.append((job[0], state["writer"].submit(save_optical_flow_to_hdf5, *job)))
 
     def reap(block):
-        # at most two studies wait for the writer: a faster solver must not pile finished studies up in host memory
-        while pending and (block or len(pending) > 2 or pending[0][1].done()):
+        # at most a few studies wait for the writer: a faster solver must not pile finished studies up in host memory
+        while pending and (block or len(pending) > (n_writers + 1 if state["proc"] else 2) or pending[0][1].done()):
             path, fut = pending.pop(0)
             try:
                 fut.result()
@@ -319,13 +386,23 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 logger.warning(f"File extension must be one of {extensions}, found {ext}, skipping")
                 continue
             todo.append((filename, stem, save_path))
-        ahead = reader_pool.submit(prepare, todo[0][0]) if todo else None
+        start_pools(len(todo))
+        depth = n_readers if state["proc"] else 1               # studies the reader stage may be ahead of the solver
+        futs = {}
+
+        def submit(k):
+            if k < len(todo) and k not in futs:
+                futs[k] = state["reader_pool"].submit(_prepare_study, reader, os.path.join(dcm_folder, todo[k][0]), mode, flipLR, cfg_masks, state["proc"])
+        for k in range(min(depth, len(todo))):
+            submit(k)
         for k, (filename, stem, save_path) in enumerate(todo):
             if verbose:
                 logger.info(f"Processing file: {filename}...")
-            mine_fut, ahead = ahead, (reader_pool.submit(prepare, todo[k + 1][0]) if k + 1 < len(todo) else None)
+            submit(k + depth)
             try:
-                nparr, md, pid, hr, masks_ahead = mine_fut.result()
+                nparr, md, pid, hr, masks_ahead, echo = futs.pop(k).result()
+                if echo is not None:
+                    echo_of[save_path] = echo
                 if model is None:
                     model = flow_model if flow_model is not None else make_flow_model(OF_algo, config, device_id)
                 waveforms = None                                       # process_video loads and validates them (reference :602-620)
@@ -342,8 +419,9 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
             reap(block=False)
         reap(block=True)
     finally:
-        writer.shutdown(wait=True)
-        reader_pool.shutdown(wait=True)
+        for pool in (state["writer"], state["reader_pool"]):
+            if pool is not None and shared is None:
+                pool.shutdown(wait=True)
         if own and model is not None:
             model.close()
     return errors

@@ -159,3 +159,55 @@ def test_segmentor_plumbing_runs_through_process_video(oracle):
     from tee_optical_flow_amd.exceptions import ConfigurationError
     with pytest.raises(ConfigurationError):
         process_video(None, None, None, mode="A4C", no_saliency=True, nparr=nparr, flow_model=m)
+
+
+PROC_DRIVER = r"""
+import sys, json, os, numpy as np
+sys.path.insert(0, ROOT)
+import h5py
+from tee_optical_flow_amd.pipeline import process_folder
+from tee_optical_flow_amd.synth import speckle_sequence
+
+class FakeModel:                        # cv2-protocol stand-in, tests only
+    def calc_batch(self, frames, scale=1.0):
+        d = (frames[1:].astype(np.float32) - frames[:-1].astype(np.float32)) / 64
+        return np.stack([d, -0.5 * d], -1) * np.float32(scale)
+    def close(self): pass
+
+if __name__ == "__main__":
+    src = os.path.join(TMP, "in"); os.makedirs(src)
+    for k in range(4):
+        g = speckle_sequence(300 + k, 5, 48, 56)
+        np.savez(os.path.join(src, f"s{k}.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.05, frame_rate=40.0, patient_id=f"P{k}", heart_rate=70)
+    open(os.path.join(src, "s9.npz"), "wb").write(b"broken")
+    kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), flow_model=FakeModel())
+    e1 = process_folder(src, os.path.join(TMP, "thr"), None, workers="thread", **kw)
+    e2 = process_folder(src, os.path.join(TMP, "prc"), None, workers="process", n_readers=2, n_writers=2, **kw)
+    same = True
+    for k in range(4):
+        with h5py.File(os.path.join(TMP, "thr", f"s{k}.hdf5"), "r") as a, h5py.File(os.path.join(TMP, "prc", f"s{k}.hdf5"), "r") as b:
+            same &= sorted(a.keys()) == sorted(b.keys())
+            for key in a.keys():
+                same &= a[key].dtype == b[key].dtype and a[key].shape == b[key].shape and bool(np.array_equal(a[key][...], b[key][...]))
+                same &= a[key].compression == b[key].compression and a[key].compression_opts == b[key].compression_opts and a[key].chunks == b[key].chunks
+            for n, v in a["flow"].attrs.items():
+                w = b["flow"].attrs[n]
+                same &= bool(np.array_equal(np.asarray(v), np.asarray(w))) and type(v) is type(w)
+    print(json.dumps({"e1": e1, "e2": e2, "same": bool(same), "files": sorted(os.listdir(os.path.join(TMP, "prc")))}, default=str))
+"""
+
+
+def test_process_folder_worker_processes_write_the_same_files(tmp_path):
+    """workers='process': the reader/mask stage and the deflate/write stage run in spawned worker processes (the echo dataset is made in
+    the reader stage, float16 flow travels to the writer); datasets, filters, chunks and attributes equal the thread form's, a broken
+    study is reported the same way."""
+    if not os.path.exists(PY_H5):
+        pytest.skip("no interpreter with h5py")
+    script = tmp_path / "drv.py"
+    script.write_text(PROC_DRIVER.replace("ROOT", repr(ROOT)).replace("TMP", repr(str(tmp_path))))
+    r = subprocess.run([PY_H5, str(script)], capture_output=True, text=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = json.loads(r.stdout.strip().splitlines()[-1])
+    assert g["same"] is True
+    assert g["files"] == ["s0.hdf5", "s1.hdf5", "s2.hdf5", "s3.hdf5"]
+    assert [e[0] for e in g["e1"]] == ["s9.npz"] and [e[0] for e in g["e2"]] == ["s9.npz"]

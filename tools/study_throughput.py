@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--frames", type=int, default=65)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--algo", default="TVL1")
+    ap.add_argument("--readers", type=int, default=2)
+    ap.add_argument("--writers", type=int, default=2)
     a = ap.parse_args()
     from tee_optical_flow_amd import pipeline as P
     from tee_optical_flow_amd import hdf5_out
@@ -31,11 +33,18 @@ def main():
     for k in range(a.studies):
         g = speckle_sequence(500 + k, a.frames, a.size, a.size)
         np.savez(os.path.join(src, f"study{k:02d}.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.04, frame_rate=50.0, patient_id=f"S{k}")
+    # the worker processes must exist before anything in this process touches the GPU
+    workers = P.StudyWorkers(a.readers, a.writers)
     model = P.make_flow_model(a.algo)
     kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo=a.algo, flow_model=model)
-    P.process_folder(src, os.path.join(tmp, "warm"), None, process_subset=True, file_subset_list=["study00.npz"], **kw)   # warm-up: allocations, masks code paths
+    P.process_folder(src, os.path.join(tmp, "warm"), None, process_subset=True, file_subset_list=["study00.npz"], workers="thread", **kw)   # warm-up: allocations, masks code paths
+    P.process_folder(src, os.path.join(tmp, "warm2"), None, process_subset=True, file_subset_list=["study00.npz", "study01.npz"], workers=workers, **kw)
     t0 = time.perf_counter()
-    errs = P.process_folder(src, os.path.join(tmp, "overlapped"), None, **kw)
+    errs_p = P.process_folder(src, os.path.join(tmp, "processes"), None, workers=workers, **kw)
+    t_proc = time.perf_counter() - t0
+    workers.close()
+    t0 = time.perf_counter()
+    errs = P.process_folder(src, os.path.join(tmp, "overlapped"), None, workers="thread", **kw)
     t_overlap = time.perf_counter() - t0
     # the same walk with the HDF5 write done in line (what the reference does): time the writer by making defer synchronous
     real = hdf5_out.save_optical_flow_to_hdf5
@@ -61,7 +70,8 @@ def main():
     model.close()
     sz = sum(os.path.getsize(os.path.join(tmp, "overlapped", f)) for f in os.listdir(os.path.join(tmp, "overlapped"))) / a.studies / 1e6
     print(f"{a.algo}: {a.studies} studies of {a.frames} frames {a.size}x{a.size} (errors: {errs})")
-    print(f"  writer thread beside the next solve: {t_overlap:6.2f} s = {t_overlap / a.studies * 1e3:7.1f} ms per study, {a.studies * (a.frames - 1) / t_overlap:7.1f} pairs/s end to end")
+    print(f"  {a.readers} reader + {a.writers} writer PROCESSES      : {t_proc:6.2f} s = {t_proc / a.studies * 1e3:7.1f} ms per study, {a.studies * (a.frames - 1) / t_proc:7.1f} pairs/s end to end (errors: {errs_p})")
+    print(f"  reader / writer threads            : {t_overlap:6.2f} s = {t_overlap / a.studies * 1e3:7.1f} ms per study, {a.studies * (a.frames - 1) / t_overlap:7.1f} pairs/s end to end")
     print(f"  write in line (reference order)    : {t_serial:6.2f} s = {t_serial / a.studies * 1e3:7.1f} ms per study, of which HDF5 gzip-9 write {t_write[0] / a.studies * 1e3:7.1f} ms; file {sz:.1f} MB per study")
     shutil.rmtree(tmp, ignore_errors=True)
 
