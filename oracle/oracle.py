@@ -73,6 +73,7 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_resize_linear.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_resize_cuda.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_double, C.c_double]
         L.orc_scaled_size.argtypes = [C.c_int, C.c_double]
         L.orc_scaled_size.restype = C.c_int
         L.orc_centered_gradient.argtypes = [fp, C.c_int, C.c_int, fp, fp]
@@ -123,6 +124,19 @@ def resize_linear(src, dw, dh, inv_scale_x=None, inv_scale_y=None):
         inv_scale_y = dh / sh
     dst = np.empty((dh, dw), np.float32)
     lib().orc_resize_linear(src, sw, sh, dst, dw, dh, float(inv_scale_x), float(inv_scale_y))
+    return dst
+
+
+def resize_cuda(src, dw, dh, inv_scale_x=None, inv_scale_y=None):
+    """cv::cuda::resize INTER_LINEAR sampling (variant 1 only, [UPSTREAM-FROM-MEMORY]): no half-pixel shift, replicate at the far edges."""
+    src = _f32(src)
+    sh, sw = src.shape
+    if inv_scale_x is None:
+        inv_scale_x = dw / sw
+    if inv_scale_y is None:
+        inv_scale_y = dh / sh
+    dst = np.empty((dh, dw), np.float32)
+    lib().orc_resize_cuda(src, sw, sh, dst, dw, dh, float(inv_scale_x), float(inv_scale_y))
     return dst
 
 

@@ -47,8 +47,9 @@
  * inner*outer (300) per warp, no median filtering, the convergence sum evaluated only on odd iterations and only once
  * the running `prevError` has dropped below the threshold, and a warp that samples I1, I1x, I1y with a weight-normalised
  * Catmull-Rom (A = -0.5) bicubic over ceil(w-2)..floor(w+2) taps with clamp addressing instead of cv::remap.
- * Not modelled: cuda::resize's own sampling rule for the pyramid / flow upsampling (the CPU forms are kept), nvcc's
- * default FMA contraction, cuda::sum's reduction order (D1's exact sum is used).
+ * Round 4: the pyramid and the flow upsampling of variant 1 sample as cuda::resize's INTER_LINEAR kernel does (orc_resize_cuda: no
+ * half-pixel shift, replicate at the far edges), also [UPSTREAM-FROM-MEMORY].  Not modelled: nvcc's default FMA contraction,
+ * cuda::sum's reduction order (D1's exact sum is used), the texture path cuda::resize may take for some sizes.
  */
 #include <float.h>
 #include <math.h>
@@ -147,6 +148,39 @@ ORC_API void orc_resize_linear(const float* src, int sw, int sh, float* dst, int
         }
     }
     free(xofs); free(a1s); free(tail);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* cv::cuda::resize(..., INTER_LINEAR) on CV_32FC1 as cudawarping's resize_linear kernel samples   */
+/* ([UPSTREAM-FROM-MEMORY], used by variant 1 only): NO half-pixel shift, replicate at the right /  */
+/* bottom edge, four weighted taps accumulated in float in this order:                             */
+/*   src_x = dx * (float)(1/fx);  x1 = floor(src_x), x2 = x1 + 1, x2r = min(x2, W-1)  (same in y)   */
+/*   out = S(y1,x1)*((x2-src_x)*(y2-src_y)) + S(y1,x2r)*((src_x-x1)*(y2-src_y))                     */
+/*       + S(y2r,x1)*((x2-src_x)*(src_y-y1)) + S(y2r,x2r)*((src_x-x1)*(src_y-y1))                   */
+/* (nvcc would contract the multiply-adds into FMAs; not modelled, deviation D3 as everywhere.)      */
+/* ------------------------------------------------------------------------------------------- */
+ORC_API void orc_resize_cuda(const float* src, int sw, int sh, float* dst, int dw, int dh, double inv_scale_x, double inv_scale_y)
+{
+    const float scale_x = (float)(1.0 / inv_scale_x), scale_y = (float)(1.0 / inv_scale_y);
+#pragma omp parallel for schedule(static)
+    for (int dy = 0; dy < dh; ++dy) {
+        const float src_y = (float)dy * scale_y;
+        int y1 = (int)floorf(src_y);
+        if (y1 > sh - 1) y1 = sh - 1;
+        const int y2 = y1 + 1, y2r = y2 < sh - 1 ? y2 : sh - 1;
+        for (int dx = 0; dx < dw; ++dx) {
+            const float src_x = (float)dx * scale_x;
+            int x1 = (int)floorf(src_x);
+            if (x1 > sw - 1) x1 = sw - 1;
+            const int x2 = x1 + 1, x2r = x2 < sw - 1 ? x2 : sw - 1;
+            float out = 0.f;
+            out = out + src[(size_t)y1 * sw + x1] * (((float)x2 - src_x) * ((float)y2 - src_y));
+            out = out + src[(size_t)y1 * sw + x2r] * ((src_x - (float)x1) * ((float)y2 - src_y));
+            out = out + src[(size_t)y2r * sw + x1] * (((float)x2 - src_x) * (src_y - (float)y1));
+            out = out + src[(size_t)y2r * sw + x2r] * ((src_x - (float)x1) * (src_y - (float)y1));
+            dst[(size_t)dy * dw + dx] = out;
+        }
+    }
 }
 
 /* dsize for resize(src, Size(), f, f): saturate_cast<int>(ssize*f) == cvRound (half-to-even) */
@@ -544,8 +578,9 @@ static int tvl1_core(const orc_params* P, const uint8_t* I0u8, const uint8_t* I1
         if (ws[s] < 1 || hs[s] < 1) { nscales = s; break; }
         const size_t n = (size_t)ws[s] * hs[s];
         I0s[s] = (float*)malloc(n * 4); I1s[s] = (float*)malloc(n * 4);
-        orc_resize_linear(I0s[s - 1], ws[s - 1], hs[s - 1], I0s[s], ws[s], hs[s], P->scale_step, P->scale_step);
-        orc_resize_linear(I1s[s - 1], ws[s - 1], hs[s - 1], I1s[s], ws[s], hs[s], P->scale_step, P->scale_step);
+        /* variant 1: the CUDA class builds its pyramid with cuda::resize(.., Size(), scaleStep, scaleStep) */
+        (P->variant == 1 ? orc_resize_cuda : orc_resize_linear)(I0s[s - 1], ws[s - 1], hs[s - 1], I0s[s], ws[s], hs[s], P->scale_step, P->scale_step);
+        (P->variant == 1 ? orc_resize_cuda : orc_resize_linear)(I1s[s - 1], ws[s - 1], hs[s - 1], I1s[s], ws[s], hs[s], P->scale_step, P->scale_step);
         if (ws[s] < 16 || hs[s] < 16) { nscales = s; break; }
         u1s[s] = (float*)malloc(n * 4); u2s[s] = (float*)malloc(n * 4);
         if (use_gamma) u3s[s] = (float*)malloc(n * 4);
@@ -570,8 +605,9 @@ static int tvl1_core(const orc_params* P, const uint8_t* I0u8, const uint8_t* I1
             }
         if (s == 0) break;
         const double isx = (double)ws[s - 1] / ws[s], isy = (double)hs[s - 1] / hs[s];
-        orc_resize_linear(u1s[s], ws[s], hs[s], u1s[s - 1], ws[s - 1], hs[s - 1], isx, isy);
-        orc_resize_linear(u2s[s], ws[s], hs[s], u2s[s - 1], ws[s - 1], hs[s - 1], isx, isy);
+        /* variant 1: cuda::resize(u, u_finer, size(finer level)) -- fx = dsize / ssize, then the same sampling rule */
+        (P->variant == 1 ? orc_resize_cuda : orc_resize_linear)(u1s[s], ws[s], hs[s], u1s[s - 1], ws[s - 1], hs[s - 1], isx, isy);
+        (P->variant == 1 ? orc_resize_cuda : orc_resize_linear)(u2s[s], ws[s], hs[s], u2s[s - 1], ws[s - 1], hs[s - 1], isx, isy);
         if (use_gamma) orc_resize_linear(u3s[s], ws[s], hs[s], u3s[s - 1], ws[s - 1], hs[s - 1], isx, isy);
         const float mul = (float)(1 / P->scale_step);       /* multiply(u, Scalar::all(1/scaleStep), u) */
         const size_t n = (size_t)ws[s - 1] * hs[s - 1];

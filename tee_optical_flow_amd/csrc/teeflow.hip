@@ -714,7 +714,8 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
     else hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
     for (int l = 1; l < h->nlev; ++l) {
         const double sc = 1.0 / P.scale_step;   // resize(src, Size(), fx, fy): scale = 1/fx
-        hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc);
+        hipLaunchKernelGGL(k_pyr_down, grid64x4(h->lv[l], F), dim3(256), 0, s, h->pyr[l - 1], h->lv[l - 1], h->pyr[l], h->lv[l], sc, sc,
+                           P.variant == TF_VARIANT_CUDA ? 1 : 0);
     }
     if (P.variant == TF_VARIANT_CUDA)
         for (int l = 0; l < h->nlev; ++l)
@@ -732,7 +733,8 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
         const Geom gs = h->lv[l], gd = h->lv[l - 1];
         // resize(u, size(I0s[s-1])): inv_scale = dsize/ssize, scale = 1/inv_scale
         const double sx = 1.0 / ((double)gd.w / gs.w), sy = 1.0 / ((double)gd.h / gs.h);
-        hipLaunchKernelGGL(k_flow_up, grid64x4(gd, B), dim3(256), 0, s, h->sb, h->ctl, gs, gd, sx, sy, (float)(1 / P.scale_step));
+        hipLaunchKernelGGL(k_flow_up, grid64x4(gd, B), dim3(256), 0, s, h->sb, h->ctl, gs, gd, sx, sy, (float)(1 / P.scale_step),
+                           P.variant == TF_VARIANT_CUDA ? 1 : 0);
         hipLaunchKernelGGL(k_ctl_set, dim3((B + 255) / 256), dim3(256), 0, s, h->ctl, B, 1);
     }
     hipLaunchKernelGGL(k_output, grid64x4(g0, B), dim3(256), 0, s, h->sb, h->ctl, g0, scale, dflow);

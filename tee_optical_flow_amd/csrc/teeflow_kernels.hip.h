@@ -107,24 +107,48 @@ __device__ __forceinline__ float resize_px(const float* __restrict__ S, int sw, 
     return t0 * b0 + t1 * b1;
 }
 
-// pyramid: one level down for every frame
+// cv::cuda::resize INTER_LINEAR as its resize_linear kernel samples (TF_VARIANT_CUDA only; oracle orc_resize_cuda, [UPSTREAM-FROM-MEMORY]):
+// no half-pixel shift, replicate at the far edges, four weighted taps accumulated in float in upstream's order
+__device__ __forceinline__ float resize_px_cuda(const float* __restrict__ S, int sw, int sh, int spitch, int dx, int dy, float scale_x, float scale_y)
+{
+    const float src_x = (float)dx * scale_x, src_y = (float)dy * scale_y;
+    int x1 = cv_floor_f(src_x), y1 = cv_floor_f(src_y);
+    x1 = x1 > sw - 1 ? sw - 1 : x1; y1 = y1 > sh - 1 ? sh - 1 : y1;
+    const int x2 = x1 + 1, y2 = y1 + 1, x2r = x2 < sw - 1 ? x2 : sw - 1, y2r = y2 < sh - 1 ? y2 : sh - 1;
+    const float* S1 = S + (size_t)y1 * spitch;
+    const float* S2 = S + (size_t)y2r * spitch;
+    float out = 0.f;
+    out = out + S1[x1] * (((float)x2 - src_x) * ((float)y2 - src_y));
+    out = out + S1[x2r] * ((src_x - (float)x1) * ((float)y2 - src_y));
+    out = out + S2[x1] * (((float)x2 - src_x) * (src_y - (float)y1));
+    out = out + S2[x2r] * ((src_x - (float)x1) * (src_y - (float)y1));
+    return out;
+}
+
+// pyramid: one level down for every frame (cuda_sampling: the CUDA class's cuda::resize rule, scale = (float)(1/fx))
 __global__ __launch_bounds__(256) void k_pyr_down(const float* __restrict__ src, Geom gs, float* __restrict__ dst, Geom gd,
-                                                  double scale_x, double scale_y)
+                                                  double scale_x, double scale_y, int cuda_sampling = 0)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
     if (dx >= gd.w || dy >= gd.h) return;
-    dst[(size_t)f * gd.plane + (size_t)dy * gd.pitch + dx] =
-        resize_px(src + (size_t)f * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y);
+    dst[(size_t)f * gd.plane + (size_t)dy * gd.pitch + dx] = cuda_sampling
+        ? resize_px_cuda(src + (size_t)f * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, (float)scale_x, (float)scale_y)
+        : resize_px(src + (size_t)f * gs.plane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y);
 }
 
 // flow: coarse level -> next finer level, times 1/scaleStep (resize + multiply of DualTVL1::calc)
 __global__ __launch_bounds__(256) void k_flow_up(StateBufs sb, const PairCtl* __restrict__ ctl, Geom gs, Geom gd,
-                                                 double scale_x, double scale_y, float mul)
+                                                 double scale_x, double scale_y, float mul, int cuda_sampling = 0)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (dx >= gd.w || dy >= gd.h) return;
     const int uc = ctl[b].ubase & 1;
     const size_t di = (size_t)b * gd.splane + (size_t)dy * gd.pitch + dx;
+    if (cuda_sampling) {
+        sb.u1[uc ^ 1][di] = resize_px_cuda(sb.u1[uc] + (size_t)b * gs.splane, gs.w, gs.h, gs.pitch, dx, dy, (float)scale_x, (float)scale_y) * mul;
+        sb.u2[uc ^ 1][di] = resize_px_cuda(sb.u2[uc] + (size_t)b * gs.splane, gs.w, gs.h, gs.pitch, dx, dy, (float)scale_x, (float)scale_y) * mul;
+        return;
+    }
     sb.u1[uc ^ 1][di] = resize_px(sb.u1[uc] + (size_t)b * gs.splane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
     sb.u2[uc ^ 1][di] = resize_px(sb.u2[uc] + (size_t)b * gs.splane, gs.w, gs.h, gs.pitch, dx, dy, scale_x, scale_y) * mul;
 }

@@ -101,6 +101,31 @@ def test_resize_matches_closed_form_half_pixel_bilinear(oracle):
     assert oracle.resize_linear(src, 36, 24, 0.8, 0.8).shape == (24, 36)
 
 
+def test_cuda_resize_sampling_closed_forms(oracle):
+    """cv::cuda::resize's INTER_LINEAR rule as restated for variant 1 ([UPSTREAM-FROM-MEMORY]): src = dst * (1/fx) with NO half-pixel
+    shift, so a ramp a*x + b*y maps to a*(dx*scale) + b*(dy*scale) away from the far edges, pixel (0,0) is copied, an identity-size
+    resize is the identity, and the far edge replicates the last row / column."""
+    H, W = 40, 50
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    ramp = (0.5 * xx - 0.25 * yy + 3.0).astype(np.float32)
+    dw, dh = oracle.scaled_size(W, 0.8), oracle.scaled_size(H, 0.8)
+    out = oracle.resize_cuda(ramp, dw, dh, 0.8, 0.8)
+    sc = np.float32(1.0 / 0.8)
+    sx, sy = np.arange(dw, dtype=np.float32) * sc, np.arange(dh, dtype=np.float32) * sc
+    inside = (sy[:, None] <= H - 1) & (sx[None, :] <= W - 1)
+    ref = 0.5 * sx[None, :].astype(np.float64) - 0.25 * sy[:, None].astype(np.float64) + 3.0
+    assert np.abs(out - ref)[inside].max() < 1e-4
+    assert out[0, 0] == ramp[0, 0]
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-3, 3, (H, W)).astype(np.float32)
+    assert np.array_equal(oracle.resize_cuda(img, W, H), img)                        # scale 1: every weight is 1 or 0
+    up = oracle.resize_cuda(img, 2 * W, 2 * H)                                        # scale 0.5: even pixels are copies, the last column replicates
+    assert np.array_equal(up[::2, ::2], img)
+    assert np.array_equal(up[::2, -1], img[:, -1]) and np.array_equal(up[-1, ::2], img[-1, :])
+    # and it is NOT the CPU rule (half-pixel centres)
+    assert np.abs(oracle.resize_linear(ramp, dw, dh, 0.8, 0.8) - out).max() > 0.02   # (0.5 - 0.25) * the 0.125-px half-pixel offset
+
+
 def test_divergence_is_negative_adjoint_of_forward_gradient(oracle):
     """<grad u, p> = -<u, div p> with the Appendix-A border rules, probed through orc_iterate:
     with I1wx = I1wy = 0 the threshold step is the identity, so one iteration gives u' = u + theta*div(p)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense what tools/refresh_profiles.sh left under gpurun_out/ into profiles/ (tracked):
-  <tag>_bench_{default,lanes1}_kernel_stats.csv + .json   rocprofv3 --kernel-trace --stats summaries and the lines those runs printed
+  <tag>_bench_{default,lanes1,tvl1_lanes1,deepflow_lanes1}_kernel_stats.csv + .json   rocprofv3 --kernel-trace --stats summaries and the lines those runs printed
   <tag>_bench_pmc.json                                      the line of `bench.py --pmc` (roofline.traffic measured in that run)
   hbm_traffic.json                                          FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels, tagged with the kernel source fingerprint
   <tag>_sq_counters.json                                    SQ / GRBM counters of k_iter2_rows and k_df_sor_rt: totals, per-launch means, derived shares
@@ -91,7 +91,7 @@ def main():
         DST = sys.argv[2]
         os.makedirs(DST, exist_ok=True)
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    for name in ("default", "lanes1"):
+    for name in ("default", "lanes1", "tvl1_lanes1", "deepflow_lanes1"):
         st = glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True)
         if st:
             shutil.copy(st[0], os.path.join(DST, f"{tag}_bench_{name}_kernel_stats.csv"))

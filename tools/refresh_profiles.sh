@@ -8,7 +8,7 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/collect_profiles.py <tag> condenses them into profiles/.
 # usage: bash tools/refresh_profiles.sh <round-tag, e.g. r03>
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -31,10 +31,13 @@ python3 tools/collect_profiles.py $TAG $GRAFT_REPO_ROOT/gpurun_out/collected_$TA
 cd /tmp
 run_stats default
 run_stats lanes1 --lanes 1 --no-cpu-baseline
+# one algorithm per profiled command (the combined tables need arithmetic to read per-algorithm shares)
+run_stats tvl1_lanes1 --lanes 1 --no-cpu-baseline --no-deepflow
+run_stats deepflow_lanes1 --lanes 1 --no-cpu-baseline --algo deepflow
 cd $GRAFT_REPO_ROOT
 timeout -k 10 200 python3 tools/launch_profile.py --batch 64 > $OUT/${TAG}_launch_profile_b64.txt 2>&1; echo "launch_profile rc=$?"
 [ -x tools/microbench/ablate_probe ] && (cd tools/microbench && timeout -k 10 200 ./ablate_probe > $OUT/${TAG}_ablate_probe.txt 2>&1; echo "ablate rc=$?")
 # condense on the box (the raw kernel traces and counter CSVs are tens of MB; gpurun carries at most 64 MiB back) and drop the raw files
 python3 tools/collect_profiles.py $TAG $GRAFT_REPO_ROOT/gpurun_out/collected_$TAG > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
-rm -rf $OUT/default $OUT/lanes1 $OUT/pmc_live/pmc_live_* $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_TVL1/sq? $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_deepflow/sq?
+rm -rf $OUT/default $OUT/lanes1 $OUT/tvl1_lanes1 $OUT/deepflow_lanes1 $OUT/pmc_live/pmc_live_* $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_TVL1/sq? $GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${TAG}_deepflow/sq?
 du -sh $GRAFT_REPO_ROOT/gpurun_out
