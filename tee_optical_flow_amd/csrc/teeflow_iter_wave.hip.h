@@ -8,13 +8,22 @@
 //   k_iter2_rows   a 256-thread block marches RY rows per step; the iterates of the rows in flight live in LDS, three
 //                  barriers per step, the fill of the three-stage pipeline costs 2 RY rows per strip.
 //   k_iter2_wave   a wave owns a full-width strip: lane l holds PX consecutive pixels of a row (PX = 4 / 6 / 8: levels up to
-//                  256 / 384 / 512 px wide).  The three rows in flight -- row y (first primal update), row y-1 (first dual +
-//                  second primal update), row y-2 (second dual update, store) -- live in the lane's registers; the horizontal
-//                  neighbours of a lane's first / last pixel come from the adjacent lane through DPP (wave_shr / wave_shl).
-//                  No LDS, no barrier; every row predicate is wave-uniform, so the halo rows of a strip execute only the
-//                  stages they need (a strip of R rows costs R + ~2 row-steps instead of R + 3 + 2 RY).
+//                  256 / 384 / 512 px wide).  Of the three rows in flight -- row y (first primal update), row y-1 (first dual +
+//                  second primal update), row y-2 (second dual update, store) -- rows y and y-1 live in two register sets that
+//                  swap roles (interior loop unrolled twice: no copies), row y-2 and the warp constants between a row's two primal
+//                  updates wait in lane-private LDS slots (WvPark: no barrier, a wave's LDS operations execute in order); the
+//                  horizontal neighbours of a lane's first / last pixel come from the adjacent lane through DPP (wave_shr /
+//                  wave_shl).  Every row predicate is wave-uniform, so the halo rows of a strip execute only the stages they need
+//                  (a strip of R rows costs R + ~5 short row-steps instead of R + 3 + 2 RY full ones), and the interior of a strip
+//                  (wv_step_full) has no predicate at all.
 //
-// The launch is one round of resident waves (strip_rule with RY = 1): slots = CUs x resident waves per CU.
+// Two launch forms (template parameter PF): two or three waves per SIMD that hide each other's load latency (PF = false), or ONE
+// wave per SIMD that hides its own: the loads of row y+1 are in flight while row y is worked on, in accumulation registers the compiler
+// is not told about (the landing zone, below).  k_iter3_wave (teeflow_iter3_wave.hip.h) builds on the second form.  All of them are
+// OPTIONS (tf_set_tuning "iter_variant" 4 / 5 / 6): bit-identical to k_iter2_rows and, on the whole step, no faster -- DESIGN.md
+// section 4c has the measurements and what they say.
+//
+// The launch is one round of resident waves (strip_rule_min): slots = CUs x resident waves per CU.
 #pragma once
 #include "teeflow_kernels.hip.h"
 #include <type_traits>

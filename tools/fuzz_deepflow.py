@@ -22,7 +22,7 @@ def main():
     t0 = time.time()
     for c in range(cases):
         # half of the cases are large enough for co-resident launches with several launches per level
-        big = rng.random() < 0.5
+        big = rng.random() < 0.65
         H = int(rng.integers(200, 641)) if big else int(rng.integers(26, 220))
         W = int(rng.integers(260, 641)) if big else int(rng.integers(26, 300))
         B = int(rng.choice([2, 5, 9]) if big else rng.choice([1, 2, 5, 33]))
@@ -30,12 +30,12 @@ def main():
         if rng.random() < 0.25:
             I1s[0] = I0s[0]
         eng = T.DenseFlow(algo="deepflow", max_batch=int(rng.choice([B, max(1, B // 2)])))
-        shape = int(rng.choice([1, 2, 3, 3, 3]))          # register-tile SOR: 16 x 4 / 8 x 4 bands / chosen per launch
+        shape = 3 if big else int(rng.choice([1, 2, 3, 3, 3]))   # register-tile SOR: 16 x 4 / 8 x 4 bands / chosen per launch (the co-resident form needs 3)
         fuse = int(rng.choice([0, 1, 2, 3, 4, 5, 5, 6, 7, 8]))   # sweeps per launch (0: one colour per launch)
         eng.set_tuning("sor_rt_shape", shape)
         eng.set_tuning("sor_fuse", fuse)
         eng.set_tuning("df_fuse_ds", int(rng.choice([0, 2, 2])))
-        coop = int(rng.choice([0, 1, 2, 2, 3]))            # co-resident regions (2: 128 x 64 whatever the batch size, 3: 128 x 32 for small batches), exchanging every coop_s sweeps
+        coop = int(rng.choice([1, 1, 2, 2, 3]) if big else rng.choice([0, 1, 1, 2, 2, 3]))            # co-resident regions (2: 128 x 64 whatever the batch size, 3: 128 x 32 for small batches), exchanging every coop_s sweeps
         coop_s = int(rng.choice([1, 2, 3, 4, 5, 5, 6, 7]))
         eng.set_tuning("sor_coop", coop)
         eng.set_tuning("sor_coop_s", coop_s)
