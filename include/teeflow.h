@@ -161,6 +161,16 @@ int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W
 int tf_condition_frames(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t* gray_out);
 int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, tf_stats* st);
 
+/* The reference's other preprocessing branch, no_saliency=False (calculate_optical_flow.py:559-560
+ * `cv2.saliency.StaticSaliencyFineGrained_create()`, :586 `saliency_obj.computeSaliency(nparr[i])`): the uint8 saliency map of
+ * every frame takes the place of the conditioned gray frame as the solver's input.  frames: host uint8 [N][H][W][channels],
+ * channels 3 (handed to OpenCV's BGR2GRAY in the order given, as the reference does with its RGB frames) or 1;
+ * saliency_out: host uint8 [N][H][W].  tf_calc_seq_saliency = maps + tf_calc_seq without the maps returning to the host
+ * (flow_out: [N-1][H][W][2]).  Restated from opencv-contrib's saliency module; nothing pins it (oracle/saliency_oracle.c). */
+int tf_saliency_frames(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, uint8_t* saliency_out);
+int tf_calc_seq_saliency(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float scale, float* flow_out,
+                         tf_stats* st);
+
 /* ---- radial / longitudinal projection + per-frame statistics of the reference's analysis step
  *      (optical_flow/analysis.py:89-212: calculate_comp_magnitude, calc_bidirectional_hist), float64, on the device.
  * tf_radlong_project: flow host float32 [N][H][W][2], centroids host float64 [N][2] = (row, col).  rad_out / long_out

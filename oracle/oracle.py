@@ -27,8 +27,9 @@ class OrcParams(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    libs = [_LIB_PATH, os.path.join(_HERE, "libdeepflow_oracle.so"), os.path.join(_HERE, "libteeflow_cpu.so")]
-    srcs = [os.path.join(_HERE, f) for f in ("tvl1_oracle.c", "deepflow_oracle.c", "teeflow_cpu_abi.c")]
+    libs = [_LIB_PATH, os.path.join(_HERE, "libdeepflow_oracle.so"), os.path.join(_HERE, "libsaliency_oracle.so"),
+            os.path.join(_HERE, "libteeflow_cpu.so")]
+    srcs = [os.path.join(_HERE, f) for f in ("tvl1_oracle.c", "deepflow_oracle.c", "saliency_oracle.c", "teeflow_cpu_abi.c")]
     if force or not all(os.path.exists(l) for l in libs) or \
             min(os.path.getmtime(l) for l in libs) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -370,3 +371,51 @@ def o3_calc(algo):
             raise RuntimeError("dfo_deepflow_calc (o3) failed")
         return flow
     return calc
+
+
+# ---- fine-grained static saliency (no_saliency=False preprocessing), saliency_oracle.c ----
+_slib = None
+
+
+def slib():
+    global _slib
+    if _slib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libsaliency_oracle.so"))
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.orc_saliency_fine_grained.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_saliency_fine_grained.restype = C.c_int
+        L.orc_sal_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_sal_blur3.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        L.orc_sal_integral.argtypes = [u8p, C.c_int, C.c_int, fp]
+        for f in (L.orc_sal_gray, L.orc_sal_blur3, L.orc_sal_integral):
+            f.restype = None
+        _slib = L
+    return _slib
+
+
+def saliency_fine_grained(img):
+    """uint8 [H,W,3] or [H,W] -> uint8 [H,W], what computeSaliency() of StaticSaliencyFineGrained returns as its map."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    H, W = img.shape[:2]
+    out = np.empty((H, W), np.uint8)
+    if slib().orc_saliency_fine_grained(img, H, W, ch, out) != 0:
+        raise ValueError(f"saliency oracle rejected an image of shape {img.shape}")
+    return out
+
+
+def saliency_parts(img):
+    """(gray, blurred twice, float integral image) of the same pipeline, for step-by-step tests."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    H, W = img.shape[:2]
+    L = slib()
+    g = np.empty((H, W), np.uint8); t = np.empty_like(g); b = np.empty_like(g)
+    L.orc_sal_gray(img, H, W, ch, g)
+    L.orc_sal_blur3(g, H, W, t)
+    L.orc_sal_blur3(t, H, W, b)
+    I = np.empty((H + 1, W + 1), np.float32)
+    L.orc_sal_integral(b, H, W, I)
+    return g, b, I

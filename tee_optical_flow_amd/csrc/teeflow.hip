@@ -17,6 +17,7 @@
 #include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
 #include "teeflow_wase.hip.h"
+#include "teeflow_saliency.hip.h"
 #include "../../include/teeflow.h"
 #include <rccl/rccl.h>      // types and prototypes only: librccl is loaded with dlopen when a communicator is first asked for
 #include <dlfcn.h>
@@ -1739,6 +1740,90 @@ TF_API int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W
         if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
     }
     (void)hipFree(dgray); (void)hipFree(dflow);
+    return rc;
+}
+
+namespace {
+// frames (host, uint8 [N][H][W][channels]) -> fine-grained saliency maps uint8 [N][H][W] in a fresh device buffer (caller frees).
+// Frames go through in chunks so that the work buffers (17 B per pixel) stay below ~2.3 GB whatever the study's length.
+struct SalBufs {
+    uint8_t *src = nullptr, *g0 = nullptr, *g1 = nullptr, *ion = nullptr, *ioff = nullptr;
+    int* P = nullptr; float* I = nullptr; uint16_t *mon = nullptr, *moff = nullptr; int* mx = nullptr;
+    ~SalBufs() { for (void* p : {(void*)src, (void*)g0, (void*)g1, (void*)ion, (void*)ioff, (void*)P, (void*)I, (void*)mon, (void*)moff, (void*)mx}) if (p) (void)hipFree(p); }
+};
+
+int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, uint8_t** dout)
+{
+    const size_t npx = (size_t)H * W, ipx = (size_t)(H + 1) * (W + 1);
+    if (H > 65535 || N > 65535) return fail(h, TF_ERR_UNSUPPORTED, "saliency: at most 65535 rows and 65535 frames per call");
+    size_t F = ((size_t)1 << 27) / npx;
+    F = F < 1 ? 1 : (F > (size_t)N ? (size_t)N : F);
+    HIPC(h, hipSetDevice(h->dev));
+    SalBufs b;
+    uint8_t* out = nullptr;
+    HIPC(h, hipMalloc(&b.src, F * npx * channels));
+    HIPC(h, hipMalloc(&b.g0, F * npx)); HIPC(h, hipMalloc(&b.g1, F * npx));
+    HIPC(h, hipMalloc(&b.ion, F * npx)); HIPC(h, hipMalloc(&b.ioff, F * npx));
+    HIPC(h, hipMalloc(&b.P, F * npx * sizeof(int))); HIPC(h, hipMalloc(&b.I, F * ipx * sizeof(float)));
+    HIPC(h, hipMalloc(&b.mon, F * npx * sizeof(uint16_t))); HIPC(h, hipMalloc(&b.moff, F * npx * sizeof(uint16_t)));
+    HIPC(h, hipMalloc(&b.mx, F * 4 * sizeof(int)));
+    HIPC(h, hipMalloc(&out, (size_t)N * npx));
+    hipError_t e = hipSuccess;
+    for (size_t f0 = 0; f0 < (size_t)N && e == hipSuccess; f0 += F) {
+        const int nf = (int)((size_t)N - f0 < F ? (size_t)N - f0 : F);
+        const size_t n = (size_t)nf * npx;
+        const dim3 g2((W + 255) / 256, H, nf), blk(256);
+        e = hipMemcpyAsync(b.src, frames + f0 * npx * channels, n * channels, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(b.mx, 0, (size_t)nf * 4 * sizeof(int), h->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(sal::k_sal_gray, dim3((unsigned)((n + 255) / 256)), blk, 0, h->stream, b.src, channels, n, b.g0);
+        hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, b.g0, b.g1, H, W);
+        hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, b.g1, b.g0, H, W);
+        hipLaunchKernelGGL(sal::k_sal_rowprefix, dim3(H, nf), dim3(64), 0, h->stream, b.g0, H, W, b.P);
+        hipLaunchKernelGGL(sal::k_sal_integral, dim3((W + 1 + 255) / 256, nf), blk, 0, h->stream, b.P, H, W, b.I);
+        hipLaunchKernelGGL(sal::k_sal_scales, g2, blk, 0, h->stream, b.g0, b.I, H, W, b.mon, b.moff, b.mx);
+        hipLaunchKernelGGL(sal::k_sal_mix_scales, g2, blk, 0, h->stream, b.mon, b.moff, H, W, b.ion, b.ioff, b.mx);
+        hipLaunchKernelGGL(sal::k_sal_mix_onoff, g2, blk, 0, h->stream, b.ion, b.ioff, H, W, b.mx, out + f0 * npx);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);     // b.src is refilled by the next chunk
+    }
+    if (e != hipSuccess) { (void)hipFree(out); return fail(h, TF_ERR_HIP, "saliency: %s", hipGetErrorString(e)); }
+    *dout = out;
+    return TF_OK;
+}
+}  // namespace
+
+TF_API int tf_saliency_frames(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, uint8_t* saliency_out)
+{
+    if (!h || !frames || !saliency_out || N < 1 || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    if (channels != 1 && channels != 3) return fail(h, TF_ERR_INVALID_ARG, "saliency: frames must have 1 or 3 channels, got %d", channels);
+    uint8_t* d = nullptr;
+    int rc = saliency_to_device(h, frames, N, H, W, channels, &d);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(saliency_out, d, (size_t)N * H * W, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    return TF_OK;
+}
+
+TF_API int tf_calc_seq_saliency(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float scale, float* flow_out, tf_stats* st)
+{
+    if (!h || !frames || !flow_out || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    if (channels != 1 && channels != 3) return fail(h, TF_ERR_INVALID_ARG, "saliency: frames must have 1 or 3 channels, got %d", channels);
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    uint8_t* dsal = nullptr;
+    int rc = saliency_to_device(h, frames, N, H, W, channels, &dsal);
+    if (rc) return rc;
+    float* dflow = nullptr;
+    const size_t fbytes = (size_t)(N - 1) * H * W * 2 * sizeof(float);
+    hipError_t e = hipMalloc(&dflow, fbytes);
+    if (e != hipSuccess) { (void)hipFree(dsal); return fail(h, TF_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    rc = calc_entry(h, MODE_SEQ, dsal, nullptr, N - 1, H, W, scale, dflow, true, st);
+    if (!rc) {
+        e = hipMemcpy(flow_out, dflow, fbytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dsal); (void)hipFree(dflow);
     return rc;
 }
 

@@ -235,6 +235,37 @@ class DenseFlow:
         self._finish(st)
         return out
 
+    def saliency_frames(self, nparr):
+        """cv2.saliency.StaticSaliencyFineGrained_create().computeSaliency(frame)[1] for every frame, on the device (reference
+        calculate_optical_flow.py:559-560, :586): uint8 [N,H,W,3] or [N,H,W] -> uint8 [N,H,W].  Three-channel frames meet
+        OpenCV's BGR2GRAY in the order given, as the reference's RGB frames do."""
+        nparr = np.ascontiguousarray(nparr)
+        if nparr.ndim == 3:
+            nparr = _u8_image_stack(nparr, "nparr", 3)
+            ch = 1
+        else:
+            nparr = _u8_image_stack(nparr, "nparr", 4)
+            ch = nparr.shape[3]
+            if ch not in (1, 3):
+                raise OpticalFlowCalculationError(f"nparr must be [N,H,W], [N,H,W,1] or [N,H,W,3], got {nparr.shape}")
+        N, H, W = nparr.shape[:3]
+        out = np.empty((N, H, W), np.uint8)
+        _lib.check(self._L.tf_saliency_frames(self._h, nparr.ctypes.data, N, H, W, ch, out.ctypes.data), self._h, "tf_saliency_frames")
+        return out
+
+    def calc_study_saliency(self, nparr, scale=1.0):
+        """RGB study uint8 [N,H,W,3] -> float32 [N-1,H,W,2] with the saliency maps as the solver's frames (no_saliency=False)."""
+        nparr = _u8_image_stack(nparr, "nparr", 4)
+        if nparr.shape[3] not in (1, 3) or nparr.shape[0] < 2:
+            raise OpticalFlowCalculationError(f"nparr must be [N>=2,H,W,3], got {nparr.shape}")
+        N, H, W, ch = nparr.shape
+        out = self._out((N - 1, H, W, 2))
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_calc_seq_saliency(self._h, nparr.ctypes.data, N, H, W, ch, float(scale), out.ctypes.data, C.byref(st)),
+                   self._h, "tf_calc_seq_saliency")
+        self._finish(st)
+        return out
+
     def wase_compensate(self, flows, bkgd_mask, scale=1.0):
         """Reference :647-652, 659 for every flow of a study at once, on the device: returns (flows - background[p]) * scale
         and the float32 backgrounds.  flows float32 [P,H,W,2]; bkgd_mask bool [N,H,W,2] (mask_dict['bkgd'])."""

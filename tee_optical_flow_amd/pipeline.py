@@ -72,13 +72,20 @@ def _compensate(flow, mask_dict, bkgd_comp):
     return flow - background
 
 
-def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conversion_factor=1.0, nparr_rgb=None):
+def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conversion_factor=1.0, nparr_rgb=None, saliency=False):
     """Reference :584-600 for already-conditioned uint8 frames [N,H,W]: N-1 flows, last one duplicated, scaled.
     All N-1 pairs are solved by ONE batched call (tf_calc_seq); background compensation (per pair) and the unit
-    scale are applied in the reference's order: (flow - background) * conversion_factor."""
+    scale are applied in the reference's order: (flow - background) * conversion_factor.
+    `saliency=True` is the no_saliency=False branch (:559-560, :586): the frames' fine-grained saliency maps, computed on the
+    device from `nparr_rgb`, are what the solver sees."""
     if bkgd_comp not in ("WASE", "none"):
         raise OpticalFlowCalculationError(f"bkgd_comp value must be [WASE, none], got {bkgd_comp}!")
-    if nparr_rgb is not None and hasattr(OF_model, "calc_study"):
+    if saliency:
+        if nparr_rgb is None or not hasattr(OF_model, "calc_study_saliency"):
+            raise OpticalFlowCalculationError("no_saliency=False needs the device engine (DenseFlow.calc_study_saliency) and the "
+                                              "study's frames; there is no CPU saliency path")
+        flows = OF_model.calc_study_saliency(nparr_rgb)          # saliency maps (:586) + all pairs on the device
+    elif nparr_rgb is not None and hasattr(OF_model, "calc_study"):
         flows = OF_model.calc_study(nparr_rgb)                   # conditioning (:588) + all pairs on the device
     else:
         flows = OF_model.calc_batch(frames_u8)                   # float32 [N-1,H,W,2]
@@ -123,9 +130,6 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
             metadata = md_file
         patient_id = patient_id or pid_file
         heart_rate = heart_rate or hr_file
-    if not no_saliency:
-        raise OpticalFlowCalculationError("cv2.saliency preprocessing is not available; use no_saliency=True "
-                                          "(what the reference's own CLI runs, calculate_optical_flow.py:737)")
     nparr = np.asarray(nparr)
     if metadata is None:
         metadata = {"pixel_spacing": None, "frame_rate": None, "R_wave_data_present": False, "R_times": None}
@@ -147,10 +151,18 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
     own = flow_model is None
     model = make_flow_model(OF_algo, config) if own else flow_model
     try:
-        on_device = hasattr(model, "calc_study") and nparr.ndim == 4 and nparr.shape[3] == 3 and nparr.dtype == np.uint8
-        frames = None if on_device else condition_frames(nparr)
-        flow_arr = flow_for_study(frames, model, mask_dict, bkgd_comp, conversion_factor,
-                                  nparr_rgb=np.ascontiguousarray(nparr) if on_device else None)
+        rgb_u8 = nparr.ndim == 4 and nparr.shape[3] == 3 and nparr.dtype == np.uint8
+        if not no_saliency:
+            # the reference's default branch (:559-560, :586): cv2.saliency.StaticSaliencyFineGrained on every frame
+            if not rgb_u8:
+                raise OpticalFlowCalculationError(f"no_saliency=False needs uint8 RGB frames [N,H,W,3], got {nparr.dtype} {nparr.shape}")
+            flow_arr = flow_for_study(None, model, mask_dict, bkgd_comp, conversion_factor,
+                                      nparr_rgb=np.ascontiguousarray(nparr), saliency=True)
+        else:
+            on_device = hasattr(model, "calc_study") and rgb_u8
+            frames = None if on_device else condition_frames(nparr)
+            flow_arr = flow_for_study(frames, model, mask_dict, bkgd_comp, conversion_factor,
+                                      nparr_rgb=np.ascontiguousarray(nparr) if on_device else None)
     finally:
         if own:
             model.close()
