@@ -72,6 +72,8 @@ class _PinnedPool:
 class DenseFlow:
     """MI355X DualTVL1 solver with the cv2.DenseOpticalFlow calling convention."""
 
+    device_unit_scale = True        # calc_study(scale=, pad_last=) applies the unit scale in the output kernel (pipeline.flow_for_study)
+
     _SETTERS = {"Tau": "tau", "Lambda": "lambda", "Theta": "theta", "ScalesNumber": "nscales",
                 "WarpingsNumber": "warps", "Epsilon": "epsilon", "InnerIterations": "inner_iterations",
                 "OuterIterations": "outer_iterations", "ScaleStep": "scale_step", "Gamma": "gamma",
@@ -222,17 +224,21 @@ class DenseFlow:
         _lib.check(self._L.tf_condition_frames(self._h, nparr.ctypes.data, N, H, W, out.ctypes.data), self._h, "tf_condition_frames")
         return out
 
-    def calc_study(self, nparr, scale=1.0):
-        """RGB study uint8 [N,H,W,3] -> float32 [N-1,H,W,2]: conditioning and all pair solves stay on the device."""
+    def calc_study(self, nparr, scale=1.0, pad_last=False):
+        """RGB study uint8 [N,H,W,3] -> float32 [N-1,H,W,2]: conditioning and all pair solves stay on the device.
+        `pad_last`: the result is [N,H,W,2] with the last flow repeated (reference :599) -- written into one pinned buffer, no
+        concatenate on the host; with `scale` = pixel_spacing * frame_rate this is the study's whole flow array (:600)."""
         nparr = _u8_image_stack(nparr, "nparr", 4)
         if nparr.shape[3] != 3 or nparr.shape[0] < 2:
             raise OpticalFlowCalculationError(f"nparr must be [N>=2,H,W,3], got {nparr.shape}")
         N, H, W, _ = nparr.shape
-        out = self._out((N - 1, H, W, 2))
+        out = self._out((N if pad_last else N - 1, H, W, 2))
         st = _lib.TfStats()
         _lib.check(self._L.tf_calc_seq_rgb(self._h, nparr.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(st)),
                    self._h, "tf_calc_seq_rgb")
         self._finish(st)
+        if pad_last:
+            out[N - 1] = out[N - 2]
         return out
 
     def saliency_frames(self, nparr):

@@ -86,16 +86,22 @@ def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conver
                                               "study's frames; there is no CPU saliency path")
         flows = OF_model.calc_study_saliency(nparr_rgb)          # saliency maps (:586) + all pairs on the device
     elif nparr_rgb is not None and hasattr(OF_model, "calc_study"):
+        if bkgd_comp == "none" and getattr(OF_model, "device_unit_scale", False):
+            # the unit scale (:600, one float32 multiply per value, the same one numpy makes) is applied by the output kernel and
+            # the last flow is repeated (:599) inside the pinned result buffer: no 136-MB concatenate and multiply on the host
+            return OF_model.calc_study(nparr_rgb, scale=conversion_factor, pad_last=True)
         flows = OF_model.calc_study(nparr_rgb)                   # conditioning (:588) + all pairs on the device
     else:
         flows = OF_model.calc_batch(frames_u8)                   # float32 [N-1,H,W,2]
+    scaled = False
     if bkgd_comp == "WASE":
         if hasattr(OF_model, "wase_compensate"):                 # device: O(N^2 H W) products, numpy's summation order kept
-            flows, _ = OF_model.wase_compensate(flows, mask_dict["bkgd"])
+            flows, _ = OF_model.wase_compensate(flows, mask_dict["bkgd"], scale=conversion_factor)   # (flow - background) * factor
+            scaled = True
         else:
             flows = np.stack([_compensate(flows[i], mask_dict, "WASE") for i in range(flows.shape[0])])
     flows = np.concatenate([flows, flows[-1:]], axis=0)          # copy last optical flow (:599)
-    return flows * conversion_factor                              # (:600)
+    return flows if scaled else flows * conversion_factor         # (:600)
 
 
 def _prep_frames(nparr, flipLR):
@@ -257,6 +263,132 @@ def dicom_to_study(ds, arr, convert_color=None):
     return arr, extract_dicom_metadata(ds), str(getattr(ds, "PatientID", "")), int(getattr(ds, "HeartRate", 0) or 0)
 
 
+# ---- shared-memory transport between process_folder's stages -------------------------------------------------------------
+# A 65-frame 512x512 study is ~50 MB of frames, ~35 MB of masks, 17 MB of `echo` and 68 MB of float16 flow.  Through the pools'
+# pipes every one of those bytes is pickled, written, read and unpickled under the caller's interpreter lock (measured: 460 of a
+# study's 700 ms in the caller's thread were spent receiving the reader stage's result).  Arrays above _SHM_MIN bytes therefore
+# travel as POSIX shared-memory blocks: the producer fills a block and sends its name, the consumer maps it; the process_folder
+# call that owns the study unlinks its blocks when the writer stage is done with them (or on any error).  If /dev/shm is too
+# small for a study (containers often give it 64 MB; writing past the limit would be a SIGBUS), that study's arrays travel
+# pickled, as before.
+_SHM_MIN = int(os.environ.get("TEEFLOW_SHM_MIN_BYTES", 1 << 20))      # (the environment reaches spawned workers; tests lower it)
+_SHM_MARGIN = 1 << 30
+_shm_stats = {"mapped": 0, "created": 0}                             # blocks this process mapped / created (tests, tools)
+
+
+def _shm_room(nbytes):
+    try:
+        st = os.statvfs("/dev/shm")
+    except OSError:
+        return False
+    return st.f_bavail * st.f_frsize > 2 * nbytes + _SHM_MARGIN
+
+
+def _shm_put(arr):
+    """ndarray -> ("shm", name, shape, dtype) with the data in a new shared-memory block (this process's mapping is closed, the block
+    stays), or the array itself when it is small / there is no room."""
+    from multiprocessing import shared_memory
+    arr = np.ascontiguousarray(arr)
+    if arr.nbytes < _SHM_MIN or not _shm_room(arr.nbytes):
+        return arr
+    blk = shared_memory.SharedMemory(create=True, size=arr.nbytes)
+    try:
+        np.ndarray(arr.shape, arr.dtype, buffer=blk.buf)[...] = arr
+    except BaseException:
+        blk.close(); blk.unlink()
+        raise
+    desc = ("shm", blk.name, arr.shape, arr.dtype.str)
+    blk.close()
+    return desc
+
+
+def _shm_new(shape, dtype):
+    """An empty shared-memory array for the caller to fill: (view, block, descriptor), or (None, None, None) without room."""
+    from multiprocessing import shared_memory
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes < _SHM_MIN or not _shm_room(nbytes):
+        return None, None, None
+    blk = shared_memory.SharedMemory(create=True, size=nbytes)
+    _shm_stats["created"] += 1
+    return np.ndarray(shape, dtype, buffer=blk.buf), blk, ("shm", blk.name, tuple(shape), np.dtype(dtype).str)
+
+
+def _is_shm(x):
+    return isinstance(x, tuple) and len(x) == 4 and x[0] == "shm"
+
+
+def _shm_get(x, blocks):
+    """Descriptor -> ndarray view (its block is appended to `blocks`, which keeps the mapping alive); anything else passes through."""
+    if not _is_shm(x):
+        return x
+    from multiprocessing import shared_memory
+    blk = shared_memory.SharedMemory(name=x[1])
+    blocks.append(blk)
+    _shm_stats["mapped"] += 1
+    return np.ndarray(x[2], np.dtype(x[3]), buffer=blk.buf)
+
+
+def _shm_release(blocks, unlink):
+    for blk in blocks:
+        try:
+            blk.close()
+        except (OSError, BufferError):                       # a view is still alive somewhere: the mapping goes with it
+            pass
+        if unlink:
+            try:
+                blk.unlink()                                  # by name: works whatever is still mapped
+            except OSError:
+                pass
+    del blocks[:]
+
+
+def _shm_unlink_names(descs):
+    """Unlink blocks this process never mapped (a study that failed before its arrays were used)."""
+    from multiprocessing import shared_memory
+    for d in descs:
+        if _is_shm(d):
+            try:
+                blk = shared_memory.SharedMemory(name=d[1])
+                blk.close(); blk.unlink()
+            except OSError:
+                pass
+
+
+def _prepare_study_shm(reader, path, mode, flipLR, config, want_echo):
+    """_prepare_study in a worker process, the big arrays returned as shared-memory descriptors."""
+    nparr, md, pid, hr, masks_ahead, echo = _prepare_study(reader, path, mode, flipLR, config, want_echo)
+    made = []
+    try:
+        nparr = _shm_put(nparr); made.append(nparr)
+        if masks_ahead is not None:
+            packed = {}
+            for k, v in masks_ahead.items():
+                packed[k] = _shm_put(v); made.append(packed[k])
+            masks_ahead = packed
+        if echo is not None:
+            echo = _shm_put(echo); made.append(echo)
+    except BaseException:
+        _shm_unlink_names(made)
+        raise
+    return nparr, md, pid, hr, masks_ahead, echo
+
+
+def _save_study_shm(job, echo, nframes):
+    """Writer stage in a worker process: map what arrived as descriptors, write the file, drop the mappings (the owner unlinks)."""
+    from .hdf5_out import save_optical_flow_to_hdf5
+    blocks = []
+    try:
+        save_path, flow_arr, nparr, mask_dict, *rest = job
+        flow_arr = _shm_get(flow_arr, blocks)
+        nparr = _shm_get(nparr, blocks)
+        mask_dict = {k: _shm_get(v, blocks) for k, v in mask_dict.items()}
+        echo = _shm_get(echo, blocks)
+        save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, *rest, echo=echo, nframes=nframes)
+        del flow_arr, nparr, mask_dict, echo
+    finally:
+        _shm_release(blocks, unlink=False)
+
+
 class StudyWorkers:
     """Worker processes for process_folder's reader/mask and deflate/write stages, for callers that hold a flow model (or a segmentor on
     the GPU) across many calls: create this object BEFORE anything in the process touches the GPU -- starting a process from a
@@ -347,7 +479,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
         n_readers, n_writers = shared.n_readers, shared.n_writers
     use_proc = workers == "process" or (workers == "auto" and flow_model is None and segmentor_model is None)
     state = {"writer": None, "reader_pool": None, "proc": False}
-    echo_of = {}
+    studies = {}                # save_path -> what of a study lives in shared memory until its writer is done
 
     def start_pools(n_todo):
         # worker processes only make sense for more than one study, and they must exist before the first GPU call of this function
@@ -367,13 +499,34 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     def defer(job):
         from .hdf5_out import save_optical_flow_to_hdf5
         if state["proc"]:
-            # the writer process needs neither the RGB frames (the reader stage made `echo` from them) nor float32 flow (the file holds float16)
+            # the writer process needs neither the RGB frames (the reader stage made `echo` from them) nor float32 flow (the file holds
+            # float16); what is big travels as shared-memory names: the flow is cast straight into a new block, the masks and `echo`
+            # stay in the blocks the reader stage filled
             save_path, flow_arr, nparr, mask_dict, *rest = job
-            echo = echo_of.pop(save_path, None)
-            job = (save_path, np.asarray(flow_arr).astype(np.float16), None if echo is not None else nparr, mask_dict, *rest)
-            pending.append((save_path, state["writer"].submit(save_optical_flow_to_hdf5, *job, echo=echo, nframes=int(np.asarray(nparr).shape[0]))))
+            study = studies.get(save_path, {})
+            echo = study.get("echo")
+            flow_arr = np.asarray(flow_arr)
+            view, blk, desc = _shm_new(flow_arr.shape, np.float16)
+            if blk is not None:
+                study.setdefault("blocks", []).append(blk)
+                view[...] = flow_arr                                # float32 -> float16 while copying
+                del view
+                flow16 = desc
+            else:
+                flow16 = flow_arr.astype(np.float16)
+            masks = study.get("mask_descs") if study.get("mask_descs") is not None and mask_dict is study.get("mask_views") else mask_dict
+            echo_d = study.get("echo_desc", echo)
+            job = (save_path, flow16, None if echo_d is not None else nparr, masks, *rest)
+            pending.append((save_path, state["writer"].submit(_save_study_shm, job, echo_d, int(np.asarray(nparr).shape[0]))))
         else:
             pending.append((job[0], state["writer"].submit(save_optical_flow_to_hdf5, *job)))
+
+    def drop_study(save_path):
+        study = studies.pop(save_path, None)
+        if study is not None:
+            for k in ("nparr", "mask_views", "echo"):
+                study.pop(k, None)
+            _shm_release(study.get("blocks", []), unlink=True)
 
     def reap(block):
         # at most a few studies wait for the writer: a faster solver must not pile finished studies up in host memory
@@ -384,6 +537,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
             except Exception as e:                                   # the writer's failure belongs to that study
                 logger.error(f"Error processing {os.path.basename(path)}: {e}")
                 errors.append((os.path.basename(path), f"{type(e).__name__}: {e}"))
+            drop_study(path)
 
     try:
         todo = []
@@ -404,17 +558,28 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
 
         def submit(k):
             if k < len(todo) and k not in futs:
-                futs[k] = state["reader_pool"].submit(_prepare_study, reader, os.path.join(dcm_folder, todo[k][0]), mode, flipLR, cfg_masks, state["proc"])
+                futs[k] = state["reader_pool"].submit(_prepare_study_shm if state["proc"] else _prepare_study, reader,
+                                                      os.path.join(dcm_folder, todo[k][0]), mode, flipLR, cfg_masks, state["proc"])
         for k in range(min(depth, len(todo))):
             submit(k)
         for k, (filename, stem, save_path) in enumerate(todo):
             if verbose:
                 logger.info(f"Processing file: {filename}...")
             submit(k + depth)
+            deferred = len(pending)
+            nparr = masks_ahead = echo = None
             try:
                 nparr, md, pid, hr, masks_ahead, echo = futs.pop(k).result()
-                if echo is not None:
-                    echo_of[save_path] = echo
+                if state["proc"]:
+                    # map what the reader stage left in shared memory; the descriptors go on to the writer stage as they are
+                    study = studies[save_path] = {"blocks": [], "descs": [nparr, echo] + list((masks_ahead or {}).values())}
+                    study["echo_desc"] = echo
+                    study["mask_descs"] = masks_ahead if masks_ahead is not None and any(_is_shm(v) for v in masks_ahead.values()) else None
+                    nparr = _shm_get(nparr, study["blocks"])
+                    if masks_ahead is not None:
+                        masks_ahead = {mk: _shm_get(mv, study["blocks"]) for mk, mv in masks_ahead.items()}
+                    study["mask_views"] = masks_ahead
+                    study["echo"] = echo = _shm_get(echo, study["blocks"]) if _is_shm(echo) else echo
                 if model is None:
                     model = flow_model if flow_model is not None else make_flow_model(OF_algo, config, device_id)
                 waveforms = None                                       # process_video loads and validates them (reference :602-620)
@@ -428,9 +593,22 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 if verbose:
                     traceback.print_exc()
                 errors.append((filename, f"{type(e).__name__}: {e}"))
+            del nparr, masks_ahead, echo
+            if len(pending) == deferred:                              # nothing was handed to the writer stage: the study's blocks go now
+                if save_path in studies and not studies[save_path]["blocks"]:
+                    _shm_unlink_names(studies[save_path].get("descs", []))
+                drop_study(save_path)
             reap(block=False)
         reap(block=True)
     finally:
+        for k, fut in futs.items():                                   # reader results nobody took (an exception above): free their blocks
+            try:
+                res = fut.result()
+                _shm_unlink_names([res[0], res[5]] + list((res[4] or {}).values()))
+            except Exception:
+                pass
+        for path in list(studies):
+            drop_study(path)
         for pool in (state["writer"], state["reader_pool"]):
             if pool is not None and shared is None:
                 pool.shutdown(wait=True)

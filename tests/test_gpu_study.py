@@ -118,3 +118,18 @@ def test_config5_full_chain_256_n32():
         f, e, hi, lo = A.calc_bidirectional_hist(arr, N)
         df, de, dhi, dlo = dev[key]
         assert np.array_equal(df, f) and np.array_equal(de, np.asarray(e)[:-1]) and np.array_equal(dhi, hi) and np.array_equal(dlo, lo)
+
+
+def test_unit_scale_and_last_flow_on_the_device_equal_the_host_order(engine):
+    """flow_for_study's device path (scale in the output kernel, last flow repeated inside the pinned buffer) gives the bits of the
+    reference's order: stack, append the last flow (:599), multiply by pixel_spacing * frame_rate (:600)."""
+    from tee_optical_flow_amd.pipeline import flow_for_study
+    from tee_optical_flow_amd.synth import speckle_sequence
+    seq = speckle_sequence(77, 6, 96, 112)
+    rgb = np.ascontiguousarray(np.repeat(seq[..., None], 3, axis=3))
+    for cf in (1.0, 0.0371 * 47.0, 3.0e-3):
+        fast = flow_for_study(None, engine, None, "none", cf, nparr_rgb=rgb)
+        flows = engine.calc_study(rgb)
+        slow = np.concatenate([flows, flows[-1:]], axis=0) * cf
+        assert fast.dtype == np.float32 and fast.shape == (6, 96, 112, 2)
+        assert np.array_equal(fast, slow)

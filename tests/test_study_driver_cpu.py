@@ -182,7 +182,10 @@ if __name__ == "__main__":
     open(os.path.join(src, "s9.npz"), "wb").write(b"broken")
     kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), flow_model=FakeModel())
     e1 = process_folder(src, os.path.join(TMP, "thr"), None, workers="thread", **kw)
+    shm_before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
     e2 = process_folder(src, os.path.join(TMP, "prc"), None, workers="process", n_readers=2, n_writers=2, **kw)
+    shm_left = sorted((set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()) - shm_before)
+    from tee_optical_flow_amd import pipeline
     same = True
     for k in range(4):
         with h5py.File(os.path.join(TMP, "thr", f"s{k}.hdf5"), "r") as a, h5py.File(os.path.join(TMP, "prc", f"s{k}.hdf5"), "r") as b:
@@ -193,21 +196,27 @@ if __name__ == "__main__":
             for n, v in a["flow"].attrs.items():
                 w = b["flow"].attrs[n]
                 same &= bool(np.array_equal(np.asarray(v), np.asarray(w))) and type(v) is type(w)
-    print(json.dumps({"e1": e1, "e2": e2, "same": bool(same), "files": sorted(os.listdir(os.path.join(TMP, "prc")))}, default=str))
+    print(json.dumps({"e1": e1, "e2": e2, "same": bool(same), "files": sorted(os.listdir(os.path.join(TMP, "prc"))),
+                      "shm_left": shm_left, "shm": pipeline._shm_stats}, default=str))
 """
 
 
 def test_process_folder_worker_processes_write_the_same_files(tmp_path):
     """workers='process': the reader/mask stage and the deflate/write stage run in spawned worker processes (the echo dataset is made in
-    the reader stage, float16 flow travels to the writer); datasets, filters, chunks and attributes equal the thread form's, a broken
+    the reader stage, float16 flow travels to the writer, everything big through shared memory); datasets, filters, chunks and attributes equal the thread form's, a broken
     study is reported the same way."""
     if not os.path.exists(PY_H5):
         pytest.skip("no interpreter with h5py")
     script = tmp_path / "drv.py"
     script.write_text(PROC_DRIVER.replace("ROOT", repr(ROOT)).replace("TMP", repr(str(tmp_path))))
-    r = subprocess.run([PY_H5, str(script)], capture_output=True, text=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    # 1 KB threshold: these small studies' frames, masks, echo and flow all travel as shared-memory blocks, as real studies' do
+    r = subprocess.run([PY_H5, str(script)], capture_output=True, text=True,
+                       env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1", "TEEFLOW_SHM_MIN_BYTES": "1024"})
     assert r.returncode == 0, r.stderr[-3000:]
+    assert "leaked shared_memory" not in r.stderr, r.stderr[-2000:]
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert g["same"] is True
     assert g["files"] == ["s0.hdf5", "s1.hdf5", "s2.hdf5", "s3.hdf5"]
     assert [e[0] for e in g["e1"]] == ["s9.npz"] and [e[0] for e in g["e2"]] == ["s9.npz"]
+    assert g["shm_left"] == [], "shared-memory blocks left behind"
+    assert g["shm"]["mapped"] == 4 * 3 and g["shm"]["created"] == 4      # per study: frames + otsu mask + echo mapped, float16 flow created

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--algo", default="TVL1")
     ap.add_argument("--readers", type=int, default=2)
     ap.add_argument("--writers", type=int, default=2)
+    ap.add_argument("--stages", action="store_true", help="also print where the caller's thread spends a study in the worker-process walk")
     a = ap.parse_args()
     from tee_optical_flow_amd import pipeline as P
     from tee_optical_flow_amd import hdf5_out
@@ -39,9 +40,39 @@ def main():
     kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo=a.algo, flow_model=model)
     P.process_folder(src, os.path.join(tmp, "warm"), None, process_subset=True, file_subset_list=["study00.npz"], workers="thread", **kw)   # warm-up: allocations, masks code paths
     P.process_folder(src, os.path.join(tmp, "warm2"), None, process_subset=True, file_subset_list=["study00.npz", "study01.npz"], workers=workers, **kw)
+    # where the caller's thread spends a study in the worker-process walk: solve (flow_for_study), hand-over to the writer (defer),
+    # the rest of process_video, and everything outside it (waiting for the reader stage, reaping writers)
+    acc = {"video": 0.0, "flow": 0.0, "defer": 0.0}
+    real_pv, real_ffs = P.process_video, P.flow_for_study
+
+    def timed_ffs(*args, **kwargs):
+        t = time.perf_counter()
+        try:
+            return real_ffs(*args, **kwargs)
+        finally:
+            acc["flow"] += time.perf_counter() - t
+
+    def timed_pv(*args, **kwargs):
+        d = kwargs.get("_defer_save")
+        if d is not None:
+            def timed_defer(job):
+                t = time.perf_counter(); d(job); acc["defer"] += time.perf_counter() - t
+            kwargs["_defer_save"] = timed_defer
+        t = time.perf_counter()
+        try:
+            return real_pv(*args, **kwargs)
+        finally:
+            acc["video"] += time.perf_counter() - t
+    if a.stages:
+        P.process_video, P.flow_for_study = timed_pv, timed_ffs
     t0 = time.perf_counter()
     errs_p = P.process_folder(src, os.path.join(tmp, "processes"), None, workers=workers, **kw)
     t_proc = time.perf_counter() - t0
+    P.process_video, P.flow_for_study = real_pv, real_ffs
+    if a.stages:
+        n = a.studies
+        print(f"  caller's thread per study (worker-process walk): solve {acc['flow'] / n * 1e3:.1f} ms, hand-over to the writer {acc['defer'] / n * 1e3:.1f} ms, "
+              f"rest of process_video {(acc['video'] - acc['flow'] - acc['defer']) / n * 1e3:.1f} ms, outside it (reader wait, reaping) {(t_proc - acc['video']) / n * 1e3:.1f} ms")
     workers.close()
     t0 = time.perf_counter()
     errs = P.process_folder(src, os.path.join(tmp, "overlapped"), None, workers="thread", **kw)
