@@ -170,6 +170,8 @@ from tee_optical_flow_amd.synth import speckle_sequence
 
 class FakeModel:                        # cv2-protocol stand-in, tests only
     def calc_batch(self, frames, scale=1.0):
+        if frames.shape[1] == 40:
+            raise RuntimeError("solver failure injected for 40-row studies")
         d = (frames[1:].astype(np.float32) - frames[:-1].astype(np.float32)) / 64
         return np.stack([d, -0.5 * d], -1) * np.float32(scale)
     def close(self): pass
@@ -179,6 +181,8 @@ if __name__ == "__main__":
     for k in range(4):
         g = speckle_sequence(300 + k, 5, 48, 56)
         np.savez(os.path.join(src, f"s{k}.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.05, frame_rate=40.0, patient_id=f"P{k}", heart_rate=70)
+    g = speckle_sequence(9, 4, 40, 64)                  # a study whose SOLVE fails: its shared-memory blocks must go too
+    np.savez(os.path.join(src, "s8.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.05, frame_rate=40.0)
     open(os.path.join(src, "s9.npz"), "wb").write(b"broken")
     kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), flow_model=FakeModel())
     e1 = process_folder(src, os.path.join(TMP, "thr"), None, workers="thread", **kw)
@@ -217,6 +221,8 @@ def test_process_folder_worker_processes_write_the_same_files(tmp_path):
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert g["same"] is True
     assert g["files"] == ["s0.hdf5", "s1.hdf5", "s2.hdf5", "s3.hdf5"]
-    assert [e[0] for e in g["e1"]] == ["s9.npz"] and [e[0] for e in g["e2"]] == ["s9.npz"]
+    assert [e[0] for e in g["e1"]] == ["s8.npz", "s9.npz"] and [e[0] for e in g["e2"]] == ["s8.npz", "s9.npz"]
+    assert "injected" in g["e2"][0][1]
     assert g["shm_left"] == [], "shared-memory blocks left behind"
-    assert g["shm"]["mapped"] == 4 * 3 and g["shm"]["created"] == 4      # per study: frames + otsu mask + echo mapped, float16 flow created
+    # per study: frames + otsu mask + echo mapped, float16 flow created; the study whose solve fails maps its three and creates none
+    assert g["shm"]["mapped"] == 5 * 3 and g["shm"]["created"] == 4
