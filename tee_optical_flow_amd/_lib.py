@@ -106,8 +106,9 @@ def load():
     L.tf_calc_pairs_device.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
     L.tf_calc_seq_device.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
     L.tf_condition_frames.argtypes = [vp, vp, i32, i32, i32, vp]
-    L.tf_saliency_frames.argtypes = [vp, vp, i32, i32, i32, i32, vp]
-    L.tf_calc_seq_saliency.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
+    if "TEEFLOW_LIB" not in os.environ or hasattr(L, "tf_saliency_frames"):     # (an older A/B build may lack the round-4 entry points)
+        L.tf_saliency_frames.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.tf_calc_seq_saliency.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
     L.tf_calc_seq_rgb.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(TfStats)]
     L.tf_radlong_project.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.tf_radlong_hist.argtypes = [vp, i32, vp, i32, vp]
