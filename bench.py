@@ -7,6 +7,13 @@ per-GPU shard size of configs[2]) with all-default DualTVL1 (lambda 0.15), input
 for N > 1 -- the (u,v) fields are all-gathered over RCCL (the one exchange step north_star names), overlapped
 with the next step's compute.  value = pairs all ranks solved / max-over-ranks wall time.
 
+Steps are independent batches, and the K timed steps are bracketed by a barrier + synchronize on both sides, not separated by
+one: by default three engines (handle + stream + host thread each) take whole steps in turn (`--in-flight 3`), so that one
+step's tail overlaps the next step's start -- what a folder of studies or a stream of batches gives a deployment for free.
+`--in-flight 1` is the form rounds 1-3 measured (one engine, each step split over two lanes and joined at its end); the
+default N=1 run times it too, right after, and reports it under "steps_joined".  Every step does the same work in both forms
+(bit-identical flows: tools/pipelined_steps.py, tests/test_gpu_batches.py::test_engine_pool_gives_the_single_engines_flows).
+
 The default N=1 run then measures BASELINE configs[3] (OF_algo='deepflow', the algorithm the reference's own CLI
 hard-codes, calculate_optical_flow.py:735-739) the same way on 128 pairs and reports it under "deepflow" in the
 same JSON line.
@@ -218,7 +225,7 @@ def pmc_child_passes(algo, out_dir, tag="live"):
         d = os.path.join(out_dir, f"pmc_{tag}_{algo}_{ctr}")
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-include-regex", kern, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile",
-               "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo] + (["--batch", "128"] if algo != "TVL1" else [])
+               "--in-flight", "1", "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo] + (["--batch", "128"] if algo != "TVL1" else [])
         env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
         r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         if r.returncode != 0:
@@ -323,21 +330,32 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     import tee_optical_flow_amd as T
     H = W = a.size
     frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)       # [2B,H,W] u8, resident in HBM
-    flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    # Steps in flight.  A step is one batch of B pairs through one engine (handle + stream).  Consecutive steps are independent, so E
+    # engines take whole steps in turn (step k on engine k % E, each driven by its own host thread) and the tail of one step -- few
+    # pairs still iterating, the fine levels done -- overlaps the start of the next, as consecutive studies of a folder would.  E = 1
+    # is the older form: one engine, the step split over `--lanes` lanes that are joined at the step's end.  DeepFlow stays at E = 1:
+    # its co-resident SOR launches take every CU.  Every step's work is the same in both forms (flows bit-identical, tools/pipelined_steps.py).
+    E = max(1, a.in_flight) if algo == "TVL1" else 1
+    lanes_each = a.lanes if E == 1 else 1
+    flows = [[torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)] for _ in range(E)]
     gdev = dev if a.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
-    eng = T.DenseFlow(device_id=local_rank, max_batch=B, algo=algo)
-    eng.set_tuning("lanes", a.lanes)
+    gathered = [[torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] for _ in range(E)] if world > 1 else None
     tuning = [kv.split("=") for kv in a.tuning.split(",") if kv]
-    for k, v in tuning:
-        eng.set_tuning(k, int(v))
+    engines = []
+    for _ in range(E):
+        e_ = T.DenseFlow(device_id=local_rank, max_batch=B, algo=algo)
+        e_.set_tuning("lanes", lanes_each)
+        for k, v in tuning:
+            e_.set_tuning(k, int(v))
+        engines.append(e_)
+    eng = engines[0]                                  # the communicator, the instrumented repeats and the latency extras use this one
     # The engine runs on its own non-blocking HIP stream and every call is host-synchronous: when it returns the flows are
     # complete, so the RCCL all-gather (torch's stream) may start at once.  The opposite direction needs an explicit host
     # wait: Work.wait() only orders torch's CURRENT STREAM behind the collective, it does not block the host, and the
     # engine's stream is not ordered against either -- so before a buffer is solved into again the host waits until the
     # all-gather that read it has really finished.
     p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
-    pending = [None, None]
+    pending = {}                                      # (engine, buffer) -> the all-gather that is reading that flow buffer
     # The exchange is the library's own: tf_allgather_flows = ncclAllGather on librccl, issued on the engine's communication
     # stream (include/teeflow.h); torch.distributed only carries the 128-byte communicator id.  If RCCL cannot be set up
     # that way (or on the gloo rehearsal backend) the step falls back to torch's all_gather_into_tensor and says so.
@@ -359,31 +377,88 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             lib_comm = False
             collective = "torch.distributed.all_gather_into_tensor (another rank could not join the library communicator)"
 
-    def retire(buf):
-        if pending[buf] is not None:
+    def retire(key):
+        tk = pending.pop(key, None)
+        if tk is not None:
             if lib_comm:
-                eng.comm_wait(pending[buf])              # host-blocking: the buffer is free for the next solve
+                eng.comm_wait(tk)                        # host-blocking: the buffer is free for the next solve
             else:
-                pending[buf].wait()
+                tk.wait()
                 if dev.type == "cuda":
                     torch.cuda.current_stream(dev).synchronize()
-            pending[buf] = None
 
-    def step(k):
-        buf = k & 1
-        retire(buf)
-        st = eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
+    def issue_gather(key):
+        e_, buf = key
+        if lib_comm:
+            pending[key] = eng.allgather(flows[e_][buf].data_ptr(), flows[e_][buf].numel(), gathered[e_][buf].data_ptr())
+        else:
+            src = flows[e_][buf] if a.backend == "nccl" else flows[e_][buf].cpu()
+            pending[key] = dist.all_gather_into_tensor(gathered[e_][buf], src, async_op=True)
+
+    def slot(k):
+        return k % E, (k // E) & 1                        # step k: engine, flow buffer
+
+    def run_steps(first, n):
+        """Steps first .. first+n-1; returns their tf_stats dicts.  Solves run on E host threads (one per engine); the collectives are
+        issued by THIS thread, in step order on every rank (RCCL needs the same order everywhere), as soon as a step's solve has
+        returned -- a solve is host-synchronous, so its flows are complete by then."""
+        stats = [None] * n
+        if E == 1:
+            for i in range(n):
+                key = slot(first + i)
+                retire(key)
+                stats[i] = eng.calc_pairs_device(p0, p1, B, H, W, flows[0][key[1]].data_ptr())
+                if world > 1:
+                    issue_gather(key)
+            return stats
+        import threading
+        done = [threading.Event() for _ in range(n)]
+        free = {}                                        # step index -> set once the all-gather that read its buffer has finished
+        failed = []
+
+        def worker(e_):
+            try:
+                for i in range(n):
+                    k = first + i
+                    if k % E != e_:
+                        continue
+                    if world > 1 and (i - 2 * E) in free:
+                        free[i - 2 * E].wait()           # this buffer's previous flows have left
+                    stats[i] = engines[e_].calc_pairs_device(p0, p1, B, H, W, flows[e_][slot(k)[1]].data_ptr())
+                    done[i].set()
+            except BaseException as ex:                  # never leave the main thread or another worker waiting
+                failed.append(ex)
+                for d_ in list(done) + list(free.values()):
+                    d_.set()
         if world > 1:
-            if lib_comm:
-                pending[buf] = eng.allgather(flows[buf].data_ptr(), flows[buf].numel(), gathered[buf].data_ptr())
-            else:
-                src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
-                pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
-        return st
+            for i in range(n):
+                free[i] = threading.Event()
+        th = [threading.Thread(target=worker, args=(e_,)) for e_ in range(E)]
+        for t in th:
+            t.start()
+        for i in range(n):
+            done[i].wait()
+            if failed:
+                for f_ in free.values():
+                    f_.set()
+                break
+            if world > 1:
+                issue_gather(slot(first + i))
+                if i - E >= 0:                            # the step before it on the same engine: its all-gather has had a whole step to finish
+                    retire(slot(first + i - E))
+                    free[i - E].set()
+        if world > 1:
+            for i in range(max(0, n - E), n):             # nobody in this call waits for these; the next call's retire() does
+                free[i].set()
+        for t in th:
+            t.join()
+        if failed:
+            raise failed[0]
+        return stats
 
     def drain():
-        retire(0)
-        retire(1)
+        for key in list(pending):
+            retire(key)
 
     def fence():
         drain()
@@ -392,14 +467,14 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(warmup):
-        step(k)
+    for e_ in engines:                                    # set-up, not a step: every engine allocates its buffers
+        e_.calc_pairs_device(p0, p1, B, H, W, flows[0][0].data_ptr())
+    run_steps(0, warmup)
     fence()
     t0 = time.perf_counter()
     acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0,
            "timed_iter_bytes": 0.0, "sor_px": 0.0}
-    for k in range(steps):
-        st = step(warmup + k)
+    for st in run_steps(warmup, steps):
         acc["total_bytes"] += st["total_bytes"]; acc["inner"] += st["inner_iters_total"]; acc["outer"] += st["outer_iters_total"]
         acc["ms_device"] += st["ms_device"]; acc["timed_iter_bytes"] += st["iter_bytes"]
     fence()
@@ -408,17 +483,32 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    last_e, last_buf = slot(warmup + steps - 1)
+    last_flow = flows[last_e][last_buf]
     gather_ok = None
     if world > 1:
         # every rank's shard must have arrived intact everywhere: compare checksums of the gathered segments with the
         # checksums the owning ranks computed locally (last timed step)
-        last = (warmup + steps - 1) & 1
         bits = lambda t: t.contiguous().view(torch.int32).to(torch.int64)        # exact, order-independent: sum of the bit patterns
-        mine = bits(flows[last]).sum().reshape(1).to(gdev)
+        mine = bits(last_flow).sum().reshape(1).to(gdev)
         sums = torch.empty(world, dtype=torch.int64, device=gdev)
         dist.all_gather_into_tensor(sums, mine)
-        seg = bits(gathered[last]).view(world, -1).sum(1)
+        seg = bits(gathered[last_e][last_buf]).view(world, -1).sum(1)
         gather_ok = bool(torch.equal(seg.cpu(), sums.cpu()))
+    # The same K steps in the older form (one engine, the step split over two lanes joined at its end), for the record beside `value`
+    joined = None
+    if E > 1 and world == 1:
+        eng.set_tuning("lanes", a.lanes)
+        eng.calc_pairs_device(p0, p1, B, H, W, flows[0][0].data_ptr())
+        torch.cuda.synchronize(dev)
+        tj = time.perf_counter()
+        for k in range(steps):
+            eng.calc_pairs_device(p0, p1, B, H, W, flows[0][k & 1].data_ptr())
+        torch.cuda.synchronize(dev)
+        dj = time.perf_counter() - tj
+        joined = {"value": B * steps / dj, "unit": "frame-pairs/s", "ms_per_step": dj / steps * 1e3, "engines": 1, "lanes": a.lanes,
+                  "note": "one engine, every step split over its lanes and joined at its end (rounds 1-3 measured this form)"}
+        eng.set_tuning("lanes", lanes_each)
     # Roofline leg: the SAME K steps again, one lane, with every launch of the dominant kernel bracketed by a HIP event
     # pair on the engine's stream.  Kept out of the timed region above (the event records cost a few % of a step).
     prof = None
@@ -426,7 +516,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include the other lane's kernels
         eng.set_profile(1)
         for k in range(steps):
-            st = step(warmup + steps + k)
+            last_flow = flows[0][k & 1]
+            st = eng.calc_pairs_device(p0, p1, B, H, W, last_flow.data_ptr())
             acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
             acc["sor_px"] += st["iter_pair_steps"]
             for kk in ("ms_warp", "ms_median", "ms_misc", "ms_sched", "ms_device"):
@@ -436,7 +527,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         if algo == "TVL1":
             prof = launch_profile(eng)
         eng.set_profile(0)
-        eng.set_tuning("lanes", a.lanes)
+        eng.set_tuning("lanes", lanes_each)
 
     out = None
     if rank == 0:
@@ -567,7 +658,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                                       "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
                                    + "inputs resident in HBM; "
                                    + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
-                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}", "lanes_per_gpu": a.lanes},
+                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}", "steps_in_flight": E, "lanes_per_engine": lanes_each,
+                       "lanes_per_gpu": E * lanes_each},
             # data-independent rate of the whole job: executed pixel-iterations (pixel-sweeps) per second of the timed region
             ("px_iterations_per_s" if algo == "TVL1" else "px_sweeps_per_s"): world * acc["timed_iter_bytes"] / unit_bytes / dt,
             "roofline": roof,
@@ -587,6 +679,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         if algo != "TVL1":
             # the co-resident SOR form: launches since the engine was made, and calls that had to be repeated tiled because a launch gave up waiting
             out["sor_coresident"] = {"launches": eng.counter("coop_launches"), "calls_repeated_tiled": eng.counter("coop_aborts")}
+        if joined is not None:
+            out["steps_joined"] = joined
         out["collective"] = collective
         if gather_ok is not None:
             out["allgather_checksums_match"] = gather_ok
@@ -615,8 +709,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             n = min(cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n, algo)
             out["cpu_baseline"] = cb
-            last = warmup + steps - 1 + (0 if a.no_profile else steps)
-            got = flows[last & 1][:n].cpu().numpy()
+            got = last_flow[:n].cpu().numpy()
             out["parity_vs_oracle_max_abs_diff_on_cpu_sample"] = max(float(np.abs(got[i] - ref[i]).max()) for i in range(n))
             cvb, cvf = cv2_baseline(I0s, I1s, min(n, 4), algo)
             if cvb is None:
@@ -628,7 +721,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                     out["mean_epe_vs_opencv"] = float(np.mean(epe))
                     out["cpu_baseline"] = cvb       # the real thing replaces the restatement as THE baseline
                     out["cpu_baseline_port"] = cb
-    eng.close()
+    for e_ in engines:
+        e_.close()
     del frames, flows, gathered
     return out
 
@@ -652,6 +746,8 @@ def main():
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_live"))
     ap.add_argument("--round-tag", default="r03")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps: no single-pair latency, no PCIe step (what the counter passes profile)")
+    ap.add_argument("--in-flight", type=int, default=3, help="DualTVL1: engines that take whole steps in turn, i.e. steps in flight per GPU (each engine one lane); "
+                                                             "1 = one engine, each step split over --lanes lanes and joined at its end")
     ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")

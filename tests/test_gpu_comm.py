@@ -60,7 +60,9 @@ def test_library_rccl_allgather_one_rank(tmp_path):
     assert r.returncode == 0 and "comm ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-def test_bench_gpus_2_starts_its_own_ranks():
+@pytest.mark.parametrize("extra", [[], ["--steps", "8", "--warmup", "2", "--in-flight", "3"], ["--steps", "3", "--in-flight", "1"]],
+                         ids=["default", "8-steps-3-in-flight", "joined-steps"])
+def test_bench_gpus_2_starts_its_own_ranks(extra):
     """`python bench.py --gpus 2` from a plain shell (no torchrun, WORLD_SIZE unset) must start its ranks
     itself and print ONE line for the job.  Rehearsed on the one GPU a test box has: gloo rendezvous, both ranks on cuda:0,
     the all-gather through torch (RCCL refuses two ranks on one device) -- the launch path, the sharding, the overlap with
@@ -69,11 +71,14 @@ def test_bench_gpus_2_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
                         "--batch", "4", "--size", "96", "--steps", "2", "--warmup", "1", "--no-deepflow", "--no-cpu-baseline",
-                        "--no-profile", "--steps-only"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-profile", "--steps-only"] + extra, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    nsteps = int(extra[extra.index("--steps") + 1]) if "--steps" in extra else 2
+    assert d["n_gpus"] == 2 and d["steps"] == nsteps and d["scaling"] == "weak" and d["value"] > 0
+    # steps in flight (engines taking whole steps in turn): the collectives are still issued in step order by one thread per rank
+    assert d["config"]["steps_in_flight"] == (1 if "joined-steps" in os.environ.get("PYTEST_CURRENT_TEST", "") else 3)
     assert "all_gather" in d["collective"] and d["allgather_checksums_match"] is True
     assert d["config"]["parallelism"] == "pair-sharded x2"

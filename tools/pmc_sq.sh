@@ -18,7 +18,7 @@ EXTRA=""
 pass() {
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-include-regex "$KREGEX" --output-format csv -d $OUT/$name -o $name -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --steps-only --lanes 1 --no-deepflow --algo $ALGO $EXTRA \
+    python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --steps-only --in-flight 1 --lanes 1 --no-deepflow --algo $ALGO $EXTRA \
     > $OUT/$name.json 2> $OUT/$name.err
   echo "pass $name ($*) rc=$?"
 }
