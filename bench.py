@@ -348,7 +348,10 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         for k, v in tuning:
             e_.set_tuning(k, int(v))
         engines.append(e_)
-    eng = engines[0]                                  # the communicator, the instrumented repeats and the latency extras use this one
+    eng = engines[0]                                  # the instrumented repeats and the latency extras use this one
+    # N > 1 with steps in flight: the communicator lives on a handle of its own that never solves, so that an all-gather is ordered
+    # behind nothing but the step whose flows it carries (tf_allgather_flows waits for its handle's solve stream)
+    comm_eng = eng if (E == 1 or world == 1) else T.DenseFlow(device_id=local_rank, max_batch=1, algo=algo)
     # The engine runs on its own non-blocking HIP stream and every call is host-synchronous: when it returns the flows are
     # complete, so the RCCL all-gather (torch's stream) may start at once.  The opposite direction needs an explicit host
     # wait: Work.wait() only orders torch's CURRENT STREAM behind the collective, it does not block the host, and the
@@ -366,7 +369,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         if a.backend == "nccl" and not a.torch_collective:
             try:
                 from tee_optical_flow_amd.distributed import init_engine_comm, torch_id_exchange
-                init_engine_comm(eng, rank, world, torch_id_exchange())
+                init_engine_comm(comm_eng, rank, world, torch_id_exchange())
                 lib_comm = True
                 collective = "tf_allgather_flows: ncclAllGather issued by the library on its own stream (librccl over xGMI)"
             except Exception as e:                       # keep the N>1 run alive; the line records which path ran
@@ -381,7 +384,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         tk = pending.pop(key, None)
         if tk is not None:
             if lib_comm:
-                eng.comm_wait(tk)                        # host-blocking: the buffer is free for the next solve
+                comm_eng.comm_wait(tk)                   # host-blocking: the buffer is free for the next solve
             else:
                 tk.wait()
                 if dev.type == "cuda":
@@ -390,7 +393,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     def issue_gather(key):
         e_, buf = key
         if lib_comm:
-            pending[key] = eng.allgather(flows[e_][buf].data_ptr(), flows[e_][buf].numel(), gathered[e_][buf].data_ptr())
+            pending[key] = comm_eng.allgather(flows[e_][buf].data_ptr(), flows[e_][buf].numel(), gathered[e_][buf].data_ptr())
         else:
             src = flows[e_][buf] if a.backend == "nccl" else flows[e_][buf].cpu()
             pending[key] = dist.all_gather_into_tensor(gathered[e_][buf], src, async_op=True)
@@ -721,6 +724,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                     out["mean_epe_vs_opencv"] = float(np.mean(epe))
                     out["cpu_baseline"] = cvb       # the real thing replaces the restatement as THE baseline
                     out["cpu_baseline_port"] = cb
+    if comm_eng is not eng:
+        comm_eng.close()
     for e_ in engines:
         e_.close()
     del frames, flows, gathered
