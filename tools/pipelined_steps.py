@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--engines", type=int, default=2)
     ap.add_argument("--lanes-each", type=int, default=1)
     ap.add_argument("--algo", default="TVL1")
+    ap.add_argument("--tuning", default="", help="engine knobs for the in-flight engines, name=value,...")
     a = ap.parse_args()
     from bench import make_inputs
     B, S = a.batch, a.size
@@ -68,6 +69,9 @@ def main():
     for _ in range(a.engines):
         e = T.DenseFlow(max_batch=B, algo=a.algo)
         e.set_tuning("lanes", a.lanes_each)
+        for kv in filter(None, a.tuning.split(",")):
+            k, v = kv.split("=")
+            e.set_tuning(k, int(v))
         engs.append(e)
     dt1, f1 = run(engs, a.steps)
     same = all(np.array_equal(f.cpu().numpy(), ref) for f in f1)
