@@ -708,6 +708,18 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         tp = time.perf_counter()
         eng.calc_pairs(I0s, I1s)
         out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
+        if E > 1:
+            # the same through every engine at once (one host thread each, two calls per engine): one batch's copies run under another's solve
+            from concurrent.futures import ThreadPoolExecutor
+
+            def twice(e_):
+                e_.calc_pairs(I0s, I1s)
+                e_.calc_pairs(I0s, I1s)
+            with ThreadPoolExecutor(E) as tpool:
+                list(tpool.map(lambda e_: e_.calc_pairs(I0s, I1s), engines))      # fills each engine's pinned pool
+                tp = time.perf_counter()
+                list(tpool.map(twice, engines))
+                out["pcie_inclusive_pairs_per_s_steps_in_flight"] = 2 * E * B / (time.perf_counter() - tp)
         if world == 1 and not a.no_cpu_baseline:
             n = min(cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n, algo)
