@@ -326,6 +326,71 @@ def launch_profile(eng):
     return lv[:n], wp[:n], it[:n], ms[:n]
 
 
+def run_steps_in_flight(first, n, E, solve, issue=None, retire=None):
+    """Steps first .. first+n-1 with E of them in flight: step k is solved by engine k % E into that engine's flow buffer (k // E) & 1
+    (`solve(k)` -> its statistics; host-synchronous, so a step's flows are complete when it returns).  Every engine has its own host
+    thread; the collectives (`issue((engine, buffer))` / `retire((engine, buffer))`, None on a single rank) are called by THIS thread
+    only, `issue` in step order -- RCCL needs the same order on every rank -- and `retire` one step of the same engine later; a worker
+    does not solve into a buffer again before the all-gather that read it has been retired.  E = 1 is the plain loop.  An exception in
+    any solve is re-raised here after every thread has come home.  Returns the n statistics in step order."""
+    key = lambda k: (k % E, (k // E) & 1)
+    stats = [None] * n
+    if E == 1:
+        for i in range(n):
+            if retire:
+                retire(key(first + i))
+            stats[i] = solve(first + i)
+            if issue:
+                issue(key(first + i))
+        return stats
+    import threading
+    done = [threading.Event() for _ in range(n)]
+    free = [threading.Event() for _ in range(n)] if issue else []     # step i's buffer: the all-gather that read it has finished
+    failed = []
+
+    def worker(e_):
+        try:
+            for i in range(n):
+                if (first + i) % E != e_:
+                    continue
+                if issue and i - 2 * E >= 0:
+                    free[i - 2 * E].wait()                # this buffer's previous flows have left
+                if failed:
+                    return
+                stats[i] = solve(first + i)
+                done[i].set()
+        except BaseException as ex:                       # never leave the main thread or another worker waiting
+            failed.append(ex)
+            for d_ in done + free:
+                d_.set()
+    th = [threading.Thread(target=worker, args=(e_,)) for e_ in range(E)]
+    for t in th:
+        t.start()
+    try:
+        for i in range(n):
+            done[i].wait()
+            if failed:
+                break
+            if issue:
+                issue(key(first + i))
+                if i - E >= 0:                            # the step before it on the same engine: its all-gather has had a whole step to finish
+                    retire(key(first + i - E))
+                    free[i - E].set()
+    except BaseException as ex:
+        failed.append(ex)
+    finally:
+        for f_ in free:                                   # nobody in this call waits for the last E; the caller's drain retires them
+            f_.set()
+        if failed:
+            for d_ in done:
+                d_.set()
+        for t in th:
+            t.join()
+    if failed:
+        raise failed[0]
+    return stats
+
+
 def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, local_rank, live_pmc=None, cpu_sample=8):
     import tee_optical_flow_amd as T
     H = W = a.size
@@ -401,63 +466,12 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     def slot(k):
         return k % E, (k // E) & 1                        # step k: engine, flow buffer
 
-    def run_steps(first, n):
-        """Steps first .. first+n-1; returns their tf_stats dicts.  Solves run on E host threads (one per engine); the collectives are
-        issued by THIS thread, in step order on every rank (RCCL needs the same order everywhere), as soon as a step's solve has
-        returned -- a solve is host-synchronous, so its flows are complete by then."""
-        stats = [None] * n
-        if E == 1:
-            for i in range(n):
-                key = slot(first + i)
-                retire(key)
-                stats[i] = eng.calc_pairs_device(p0, p1, B, H, W, flows[0][key[1]].data_ptr())
-                if world > 1:
-                    issue_gather(key)
-            return stats
-        import threading
-        done = [threading.Event() for _ in range(n)]
-        free = {}                                        # step index -> set once the all-gather that read its buffer has finished
-        failed = []
+    def solve(k):
+        e_, buf = slot(k)
+        return engines[e_].calc_pairs_device(p0, p1, B, H, W, flows[e_][buf].data_ptr())
 
-        def worker(e_):
-            try:
-                for i in range(n):
-                    k = first + i
-                    if k % E != e_:
-                        continue
-                    if world > 1 and (i - 2 * E) in free:
-                        free[i - 2 * E].wait()           # this buffer's previous flows have left
-                    stats[i] = engines[e_].calc_pairs_device(p0, p1, B, H, W, flows[e_][slot(k)[1]].data_ptr())
-                    done[i].set()
-            except BaseException as ex:                  # never leave the main thread or another worker waiting
-                failed.append(ex)
-                for d_ in list(done) + list(free.values()):
-                    d_.set()
-        if world > 1:
-            for i in range(n):
-                free[i] = threading.Event()
-        th = [threading.Thread(target=worker, args=(e_,)) for e_ in range(E)]
-        for t in th:
-            t.start()
-        for i in range(n):
-            done[i].wait()
-            if failed:
-                for f_ in free.values():
-                    f_.set()
-                break
-            if world > 1:
-                issue_gather(slot(first + i))
-                if i - E >= 0:                            # the step before it on the same engine: its all-gather has had a whole step to finish
-                    retire(slot(first + i - E))
-                    free[i - E].set()
-        if world > 1:
-            for i in range(max(0, n - E), n):             # nobody in this call waits for these; the next call's retire() does
-                free[i].set()
-        for t in th:
-            t.join()
-        if failed:
-            raise failed[0]
-        return stats
+    def run_steps(first, n):
+        return run_steps_in_flight(first, n, E, solve, issue_gather if world > 1 else None, retire if world > 1 else None)
 
     def drain():
         for key in list(pending):
