@@ -14,8 +14,12 @@
  *   (batch of independent pairs, BASELINE config 3)                                              -> tf_calc_pairs
  *
  * Plain pointers and sizes only; no torch / numpy types.  The library owns all device memory and its
- * HIP stream.  One handle per device; a handle is NOT re-entrant (mirrors the cv2 object, which the
- * reference also reuses sequentially from one thread).  All functions return TF_OK (0) or an error
+ * HIP stream.  A handle is NOT re-entrant (mirrors the cv2 object, which the reference also reuses
+ * sequentially from one thread), but handles are independent of each other: several handles on ONE
+ * device may be driven from several host threads at once, each taking whole calls -- three of them
+ * solve a stream of 128-pair DualTVL1 batches 7-10 % faster than one (one batch's tail and copies run
+ * under the next batch's full launches; bench.py --in-flight, EnginePool in the Python layer).
+ * All functions return TF_OK (0) or an error
  * code; tf_last_error() gives the message (the Python layer raises OpticalFlowCalculationError,
  * reference optical_flow/exceptions.py:26-28).
  *
