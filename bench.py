@@ -771,7 +771,7 @@ def main():
     ap.add_argument("--algo", default="TVL1", choices=["TVL1", "deepflow"], help="BASELINE configs[1..2] (TVL1, default) or configs[3] (deepflow) as the main leg")
     ap.add_argument("--no-deepflow", action="store_true", help="skip the DeepFlow leg the default N=1 TVL1 run appends")
     ap.add_argument("--deepflow-batch", type=int, default=128, help="pairs per step of the DeepFlow leg (64 pairs: 577, 128: 601-607, 256: 608 pairs/s on one MI355X)")
-    ap.add_argument("--deepflow-steps", type=int, default=2)
+    ap.add_argument("--deepflow-steps", type=int, default=4)
     ap.add_argument("--pmc", action="store_true", help="N=1 only: first run the FETCH_SIZE / WRITE_SIZE counter passes of this command as child "
                                                        "processes under rocprofv3 (adds ~1-2 min), so roofline.traffic is measured in this run")
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_live"))
