@@ -117,7 +117,7 @@ def _prep_frames(nparr, flipLR):
 def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode="A4C", bkgd_comp="none", flipLR=False,
                   no_saliency=False, OF_algo="TVL1", save_mask_subset=None, include_waveforms=False, waveform_folder=None,
                   config=None, *, nparr=None, metadata=None, patient_id="", heart_rate=0, waveforms=None, flow_model=None,
-                  mask_dict=None, _defer_save=None):
+                  mask_dict=None, _defer_save=None, flow_deflate_level=None):
     """Same positional signature as the reference (:478-483).  Keyword-only extras let a caller inject what the
     offline image cannot provide: `nparr` (frames instead of a DICOM), `metadata`, `mask_dict` (segmentation result),
     `flow_model`.  Returns the float32 flow array [N,H,W,2] that was written."""
@@ -187,7 +187,7 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
             _defer_save(job)                      # process_folder: the writer thread takes it while the next study is solved
         else:
             from .hdf5_out import save_optical_flow_to_hdf5
-            save_optical_flow_to_hdf5(*job)
+            save_optical_flow_to_hdf5(*job, flow_deflate_level=flow_deflate_level)
     return flow_arr
 
 
@@ -373,7 +373,7 @@ def _prepare_study_shm(reader, path, mode, flipLR, config, want_echo):
     return nparr, md, pid, hr, masks_ahead, echo
 
 
-def _save_study_shm(job, echo, nframes):
+def _save_study_shm(job, echo, nframes, flow_deflate_level=None):
     """Writer stage in a worker process: map what arrived as descriptors, write the file, drop the mappings (the owner unlinks)."""
     from .hdf5_out import save_optical_flow_to_hdf5
     blocks = []
@@ -383,7 +383,7 @@ def _save_study_shm(job, echo, nframes):
         nparr = _shm_get(nparr, blocks)
         mask_dict = {k: _shm_get(v, blocks) for k, v in mask_dict.items()}
         echo = _shm_get(echo, blocks)
-        save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, *rest, echo=echo, nframes=nframes)
+        save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, *rest, echo=echo, nframes=nframes, flow_deflate_level=flow_deflate_level)
         del flow_arr, nparr, mask_dict, echo
     finally:
         _shm_release(blocks, unlink=False)
@@ -452,7 +452,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                    flipLR=False, verbose=True, recalculate=False, no_saliency=True, OF_algo="TVL1", save_mask_subset=None,
                    include_waveforms=False, waveform_folder=None, pixel_spacing=None, frame_rate=None, process_subset=False,
                    file_subset_list=(), *, rank=0, world=1, extensions=("dcm",), reader=read_study, flow_model=None, config=None,
-                   device_id=0, workers="auto", n_readers=None, n_writers=None):
+                   device_id=0, workers="auto", n_readers=None, n_writers=None, flow_deflate_level=None):
     """Drop-in for the reference's process_folder (:243-290), same positional signature and the same rules:
       * the folder listing is cut into `nchunks` slices of len // nchunks files, this call takes slice `chunk_index`
         (the remainder files are dropped, as the reference does -- SURVEY.md Appendix C.8);
@@ -468,7 +468,8 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     writer stages in `n_readers` + `n_writers` worker PROCESSES (spawned here, before this call's first GPU call; the mask stage and
     the deflate both hold the interpreter lock, which is why threads bought 3 %), "thread" in one thread each, "auto" takes
     processes when this call creates the flow model itself (no `flow_model`, no `segmentor_model`: nothing in the caller's hands has
-    initialised the GPU yet as far as this function can tell) and more than one study is to do.  Returns the list of
+    initialised the GPU yet as far as this function can tell) and more than one study is to do.  `flow_deflate_level` (None = 9 = the
+    reference's bytes): zlib effort for the `flow` / `echo` chunks, see hdf5_out.save_optical_flow_to_hdf5.  Returns the list of
     (filename, error string)."""
     os.makedirs(save_folder, exist_ok=True)
     file_list = sorted(os.listdir(dcm_folder))                      # os.listdir order is arbitrary; sorted = same slices on every rank
@@ -532,9 +533,9 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
             masks = study.get("mask_descs") if study.get("mask_descs") is not None and mask_dict is study.get("mask_views") else mask_dict
             echo_d = study.get("echo_desc", echo)
             job = (save_path, flow16, None if echo_d is not None else nparr, masks, *rest)
-            pending.append((save_path, state["writer"].submit(_save_study_shm, job, echo_d, int(np.asarray(nparr).shape[0]))))
+            pending.append((save_path, state["writer"].submit(_save_study_shm, job, echo_d, int(np.asarray(nparr).shape[0]), flow_deflate_level)))
         else:
-            pending.append((job[0], state["writer"].submit(save_optical_flow_to_hdf5, *job)))
+            pending.append((job[0], state["writer"].submit(save_optical_flow_to_hdf5, *job, flow_deflate_level=flow_deflate_level)))
 
     def drop_study(save_path):
         study = studies.pop(save_path, None)

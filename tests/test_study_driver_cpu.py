@@ -189,6 +189,20 @@ if __name__ == "__main__":
     shm_before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
     e2 = process_folder(src, os.path.join(TMP, "prc"), None, workers="process", n_readers=2, n_writers=2, **kw)
     shm_left = sorted((set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()) - shm_before)
+    # opt-in: flow / echo chunks stored uncompressed inside valid deflate streams -- same datasets, filters, values for any reader
+    e3 = process_folder(src, os.path.join(TMP, "lvl0"), None, workers="process", n_readers=2, n_writers=2, flow_deflate_level=0, **kw)
+    e4 = process_folder(src, os.path.join(TMP, "lvl0t"), None, workers="thread", flow_deflate_level=0, **kw)
+    same0 = [e[0] for e in e3] == ["s8.npz", "s9.npz"] and [e[0] for e in e4] == ["s8.npz", "s9.npz"]
+    bigger = True
+    for sub in ("lvl0", "lvl0t"):
+        for k in range(4):
+            with h5py.File(os.path.join(TMP, "thr", f"s{k}.hdf5"), "r") as a, h5py.File(os.path.join(TMP, sub, f"s{k}.hdf5"), "r") as b:
+                same0 &= sorted(a.keys()) == sorted(b.keys())
+                for key in a.keys():
+                    same0 &= a[key].dtype == b[key].dtype and a[key].shape == b[key].shape and bool(np.array_equal(a[key][...], b[key][...]))
+                    same0 &= a[key].compression == b[key].compression and a[key].compression_opts == b[key].compression_opts and a[key].chunks == b[key].chunks
+                bigger &= b["flow"].id.get_storage_size() > a["flow"].id.get_storage_size()
+                bigger &= b["otsu"].id.get_storage_size() == a["otsu"].id.get_storage_size()
     from tee_optical_flow_amd import pipeline
     same = True
     for k in range(4):
@@ -201,7 +215,7 @@ if __name__ == "__main__":
                 w = b["flow"].attrs[n]
                 same &= bool(np.array_equal(np.asarray(v), np.asarray(w))) and type(v) is type(w)
     print(json.dumps({"e1": e1, "e2": e2, "same": bool(same), "files": sorted(os.listdir(os.path.join(TMP, "prc"))),
-                      "shm_left": shm_left, "shm": pipeline._shm_stats}, default=str))
+                      "shm_left": shm_left, "shm": pipeline._shm_stats, "same0": bool(same0), "bigger": bool(bigger)}, default=str))
 """
 
 
@@ -225,4 +239,5 @@ def test_process_folder_worker_processes_write_the_same_files(tmp_path):
     assert "injected" in g["e2"][0][1]
     assert g["shm_left"] == [], "shared-memory blocks left behind"
     # per study: frames + otsu mask + echo mapped, float16 flow created; the study whose solve fails maps its three and creates none
-    assert g["shm"]["mapped"] == 5 * 3 and g["shm"]["created"] == 4
+    assert g["shm"]["mapped"] == 2 * 5 * 3 and g["shm"]["created"] == 2 * 4      # (the walk runs twice in worker processes: level 9 and level 0)
+    assert g["same0"] is True and g["bigger"] is True                              # flow_deflate_level=0: same content, only the flow / echo chunks grow
