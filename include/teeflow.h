@@ -14,11 +14,20 @@
  *   (batch of independent pairs, BASELINE config 3)                                              -> tf_calc_pairs
  *
  * Plain pointers and sizes only; no torch / numpy types.  The library owns all device memory and its
- * HIP stream.  A handle is NOT re-entrant (mirrors the cv2 object, which the reference also reuses
+ * HIP streams.  A handle is NOT re-entrant (mirrors the cv2 object, which the reference also reuses
  * sequentially from one thread), but handles are independent of each other: several handles on ONE
- * device may be driven from several host threads at once, each taking whole calls -- three of them
- * solve a stream of 128-pair DualTVL1 batches 7-10 % faster than one (one batch's tail and copies run
- * under the next batch's full launches; bench.py --in-flight, EnginePool in the Python layer).
+ * device may be driven from several host threads at once.
+ *
+ * Sub-batches and lanes.  A handle solves up to max_batch (128) pairs at a time.  A call that holds more
+ * -- tf_calc_pairs with 1024 pairs, tf_calc_seq on a 1025-frame study -- is cut into sub-batches that the
+ * handle's LANES (engines of their own inside the library: stream, buffers, host thread; three for
+ * DualTVL1, one for DeepFlow) take from a queue one at a time: a lane that has finished a sub-batch starts
+ * the next at once, so one sub-batch's tail (few pairs still iterating) runs under the others' full
+ * launches.  The call returns when all of its sub-batches are done (if one fails, those not yet started
+ * are dropped, the ones running finish, and the call returns the failure with nothing left in flight).
+ * tf_submit_* queue the same job without waiting (tf_wait collects it), so that consecutive batches --
+ * the studies of a folder, the steps of a stream -- keep the lanes busy across calls.  Flows and
+ * tf_get_iters are identical whichever lane solved what.
  * All functions return TF_OK (0) or an error
  * code; tf_last_error() gives the message (the Python layer raises OpticalFlowCalculationError,
  * reference optical_flow/exceptions.py:26-28).
@@ -159,6 +168,18 @@ int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s,
 int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale,
                        float* dflow_out, tf_stats* st);
 
+/* Asynchronous forms of the four calls above (the loop calculate_optical_flow.py:584-597 for SEVERAL studies / batches at a time):
+ * the job is queued on the handle's lanes and the call returns with a ticket; every buffer must stay valid and untouched until
+ * tf_wait(h, ticket, st) has returned (ticket < 0: all jobs not yet waited for, oldest first; the first failure is returned).
+ * Jobs start in submission order; sub-batches of consecutive jobs overlap.  tf_wait leaves the job's iteration counts where
+ * tf_get_iters reads them.  While jobs are in flight the synchronous tf_calc_* calls on the same handle queue behind them.
+ * uint8 frames only. */
+int tf_submit_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W, float scale, float* dflow_out, int* ticket);
+int tf_submit_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, int* ticket);
+int tf_submit_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, int* ticket);
+int tf_submit_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, int* ticket);
+int tf_wait(tf_handle* h, int ticket, tf_stats* st);
+
 /* Frame conditioning of the reference's loop, `img2uint8(rgb2gray(nparr[i]))` (calculate_optical_flow.py:588,
  * optical_flow_utils.py:30-31), on the device: rgb uint8 [N][H][W][3] -> gray uint8 [N][H][W], normalised per frame.
  * tf_calc_seq_rgb = condition + tf_calc_seq without the frames ever returning to the host (flow_out: [N-1][H][W][2]). */
@@ -228,10 +249,14 @@ int tf_device_count(void);
  * "sor_fuse" (sweeps per launch of the tiled register kernel), "sor_rt_shape" (region shape; 3 = chosen per launch), "sor_coop" (1 = all sweeps
  * of a fixed-point iteration in one launch of co-resident regions where a level needs several [default], 2 = always 128x64 regions, 3 = always
  * 128x32 regions for small batches, 0 = never), "sor_coop_small" (0 = small batches keep the tiled form), "sor_coop_s" (sweeps between two exchanges), "sor_coop_min_util" (per cent of its CUs such a launch must fill, else tiled), "df_fuse_ds" (form of the data/smoothness kernel).
- * Both: "lanes" (independent engine lanes a batch is split over). */
+ * Both: "lanes" (contiguous parts a call of at most one sub-batch is split into, joined at its end), "queue_lanes" (lanes that take whole
+ * sub-batches of larger calls and of tf_submit_* jobs from the queue: -1 = 3 for DualTVL1, 1 for DeepFlow [default]; 0 = no queue, every call is
+ * split in contiguous parts as in rounds 1-4), "queue_unit" (pairs per queued sub-batch, 0 = max_batch). */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* counters of the handle for tests and tools: "coop_launches" (launches of the co-resident SOR form since the handle was made),
- * "coop_aborts" (calls repeated with the tiled form because such a launch gave up waiting), "coop_disabled"; -1 for an unknown name */
+ * "coop_aborts" (calls repeated with the tiled form because such a launch gave up waiting), "coop_disabled"; "queue_jobs", "queue_units_done",
+ * "queue_units_skipped" (sub-batches dropped because an earlier one of their call had failed), "queue_outstanding", "queue_lanes";
+ * "experimental" (1: built with the experimental tvl1_iter forms); -1 for an unknown name */
 long long tf_dbg_counter(tf_handle* h, const char* name);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */
 int tf_dbg_df_refine(tf_handle* h, const float* I0, const float* I1, int w, int hgt, float* u, float* v);

@@ -2,8 +2,8 @@
  * oracle/teeflow_cpu_abi.c -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT PATH.
  *
  * "The same ABI is exported by the CPU oracle library."  This file puts the host-pointer core of
- * include/teeflow.h (tf_create / tf_set_param / tf_calc_pair / tf_calc_seq / tf_calc_pairs / tf_get_iters /
- * tf_last_error / tf_destroy, and tf_create_deepflow) on top of the CPU restatements in tvl1_oracle.c /
+ * include/teeflow.h (tf_create / tf_set_param / tf_calc_pair / tf_calc_seq / tf_calc_pairs / tf_submit_pairs / tf_submit_seq / tf_wait /
+ * tf_get_iters / tf_last_error / tf_destroy, and tf_create_deepflow) on top of the CPU restatements in tvl1_oracle.c /
  * deepflow_oracle.c, so that boundary-level tests can drive the checker through the very entry points the product
  * exports (same structs, same error codes, same flow / iteration-count layouts) and compare the two libraries call for
  * call.  It replaces, as a checker, the same reference interface the product does:
@@ -36,12 +36,16 @@ typedef struct {
 int orc_tvl1_calc(const orc_params* P, const uint8_t* I0, const uint8_t* I1, int H, int W, float* flow, int* iters);
 int dfo_deepflow_calc(const dfo_params* P, const uint8_t* I0, const uint8_t* I1, int H, int W, float* flow);
 
+#define MAX_TICKETS 16
 struct tf_handle {
     tf_params P;
     tf_deepflow_params DP;
     char err[256];
     int* iters; size_t n_iters;
     int last_pairs, last_nlev;
+    /* tf_submit_* jobs: solved at once (one thread of control here), kept until tf_wait */
+    struct { int used; tf_stats st; int* iters; size_t n_iters; int pairs, nlev; } job[MAX_TICKETS];
+    int next_ticket;
 };
 static char g_create_err[256];
 
@@ -112,7 +116,7 @@ API int tf_create_deepflow(const tf_deepflow_params* p, int device_id, tf_handle
     return TF_OK;
 }
 
-API void tf_destroy(tf_handle* h) { if (h) { free(h->iters); free(h); } }
+API void tf_destroy(tf_handle* h) { if (h) { for (int k = 0; k < MAX_TICKETS; ++k) free(h->job[k].iters); free(h->iters); free(h); } }
 API const char* tf_last_error(tf_handle* h) { return h ? h->err : g_create_err; }
 
 API int tf_set_param(tf_handle* h, int key, double v)
@@ -238,5 +242,48 @@ API int tf_get_iters(tf_handle* h, int* out, size_t capacity_ints, size_t* writt
     const size_t n = h->n_iters < capacity_ints ? h->n_iters : capacity_ints;
     if (n) memcpy(out, h->iters, n * sizeof(int));
     if (written) *written = n;
+    return TF_OK;
+}
+
+/* Asynchronous forms (include/teeflow.h): the checker has no lanes, so the job is solved when it is submitted and tf_wait hands its
+ * results over -- same observable protocol (tickets, order-free waiting, iteration counts after the wait). */
+static int stash(tf_handle* h, int rc, const tf_stats* st, int* ticket)
+{
+    if (rc) return rc;
+    if (!ticket) return fail(h, TF_ERR_INVALID_ARG, "ticket == NULL");
+    int k = -1;
+    for (int i = 0; i < MAX_TICKETS; ++i) if (!h->job[i].used) { k = i; break; }
+    if (k < 0) return fail(h, TF_ERR_NOMEM, "too many jobs not waited for");
+    h->job[k].used = ++h->next_ticket; h->job[k].st = *st;
+    h->job[k].iters = h->iters; h->job[k].n_iters = h->n_iters; h->job[k].pairs = h->last_pairs; h->job[k].nlev = h->last_nlev;
+    h->iters = NULL; h->n_iters = 0;
+    *ticket = h->job[k].used;
+    return TF_OK;
+}
+API int tf_submit_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, int* ticket)
+{
+    tf_stats st;
+    if (!h) return TF_ERR_INVALID_ARG;
+    return stash(h, tf_calc_pairs(h, I0s, I1s, B, H, W, flow_out, &st), &st, ticket);
+}
+API int tf_submit_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, int* ticket)
+{
+    tf_stats st;
+    if (!h) return TF_ERR_INVALID_ARG;
+    return stash(h, tf_calc_seq(h, frames, N, H, W, scale, flow_out, &st), &st, ticket);
+}
+API int tf_wait(tf_handle* h, int ticket, tf_stats* st)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    for (int pass = 0; pass < (ticket < 0 ? MAX_TICKETS : 1); ++pass) {
+        int k = -1;
+        for (int i = 0; i < MAX_TICKETS; ++i)
+            if (h->job[i].used && (ticket < 0 ? (k < 0 || h->job[i].used < h->job[k].used) : h->job[i].used == ticket)) k = i;
+        if (k < 0) { if (ticket < 0) return TF_OK; return fail(h, TF_ERR_INVALID_ARG, "unknown ticket"); }
+        free(h->iters);
+        h->iters = h->job[k].iters; h->n_iters = h->job[k].n_iters; h->last_pairs = h->job[k].pairs; h->last_nlev = h->job[k].nlev;
+        if (st) *st = h->job[k].st;
+        h->job[k].iters = NULL; h->job[k].used = 0;
+    }
     return TF_OK;
 }

@@ -11,8 +11,10 @@
 // each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
+#ifdef TF_EXPERIMENTAL       // the one-wave-per-strip forms of tvl1_iter: measured, tied or lost, kept as experiments
 #include "teeflow_iter_wave.hip.h"
 #include "teeflow_iter3_wave.hip.h"
+#endif
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
@@ -30,6 +32,9 @@
 #include <deque>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <map>
 #include <vector>
@@ -50,11 +55,66 @@ struct ProfEv { hipEvent_t a, b; int level = 0, warp = 0, it = 0; float ms = 0.f
 
 }  // namespace
 
-struct tf_handle {
+// Implementation knobs (tf_set_tuning; results never depend on them).  One struct, so that a lane gets its engine's settings with ONE
+// assignment (a knob missed in a field-by-field copy would silently make the lanes differ).
+struct LanePool;
+struct QJob;
+struct TfKnobs {
+    int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
+                                 // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
+    int force_ry = 0;            // 0 = floor(256/QX) rows per step
+    int iter_wave = 0;           // 1: batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
+                                 // instead of k_iter2_rows; 0 = never
+    int wave_max_w = 512;        // widest level the one-wave-per-strip kernels take (<= 512)
+    int wave_minrows = 8;        // k_iter2_wave: shortest strip (rows)
+    int wave_px = 0;             // k_iter2_wave: pixels per lane (4 / 6 / 8); 0 = the narrowest form that covers the level's width
+    int iter_k3 = 0;             // 1: THREE iterations per launch (k_iter3_wave) wherever k_iter2_wave applies and inner_iterations is a multiple of 3
+    int wave_pf = 0;             // k_iter2_wave: 1 = one wave per SIMD with the next row's loads in flight (three register sets), 0 = two or three waves per SIMD
+    int wave_slots = 0;          // k_iter2_wave: resident waves to size the strips for (0 = what the occupancy query says)
+    int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
+    int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
+    int tile_max_w = 0;          // levels this narrow or narrower always take the tile kernels (experiment: see DESIGN section 8)
+    int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
+    int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
+                                 // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
+    int sub_batches = 1;         // >1 cuts a host-pointer call that fits the capacity into that many sub-batches so the copy-out of
+                                 // one overlaps the solve of the next; measured at 128 pairs @512^2: smaller batches cost more (2099 /
+                                 // 2030 / 1886 / 1701 pairs/s for 1 / 2 / 3 / 4) than the 5 ms of D2H they hide.  Calls larger than
+                                 // the capacity are cut anyway and do overlap.
+    int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
+    int sor_plain_div = 0;       // tests: k_df_sor_rt takes its plain-IEEE-division path (what a block with out-of-range diagonals does)
+    int sor_rt_shape = 3;        // k_df_sor_rt: 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
+                                 // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
+    int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (non-zero: k_df_data_smooth4, four pixels per thread,
+                                 // 16-byte loads; 0: k_df_data then k_df_smooth, the plain form it is tested against)
+    int sor_coop = 1;            // DeepFlow: all sweeps of a fixed-point iteration in one launch of co-resident regions (k_df_sor_rt_coop) where a
+                                 // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form,
+                                 // 2 = 128 x 64 regions whatever the batch size and however full the launches (tests), 3 = the small-batch form
+                                 // (128 x 32 regions) whenever the batch is small, sor_coop_small or not (tests)
+    int sor_coop_min_util = 85;  // co-resident launches must be at least this full (per cent) RELATIVE to the tiled form's rounds, else the level runs
+                                 // tiled (600x800 studies: 324 pairs/s always co-resident, 357 tiled, 359 with the rule)
+    int sor_coop_small = 1;      // few pairs: co-resident 128 x 32 regions (0: the tiled form, as before)
+    int sor_coop_s = 5;          // sweeps between two exchanges of (du, dv) in that kernel (the halo is 2 x this)
+    int sor_fuse = 5;            // DeepFlow: complete red-black SOR sweeps per launch of k_df_sor_rt (0 = one colour per launch, in place).
+                                 // 64 pairs @512^2: 466 / 534 / 562 / 548 / 567 pairs/s for 3 / 4 / 5 / 6 / 7; 5 divides the 25 sweeps evenly
+    int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
+                                 // bound by the texture path (~7-10 cycles per scattered dword load and wave); from LDS the same taps cost
+                                 // ~2.  128 pairs @512^2, warp stage per step: 5.0 ms gathers, 3.35 / 3.5 / 3.55 / 3.8 ms for M = 4 / 8 / 12 /
+                                 // 16 (+3.4 % pairs/s).  A pixel displaced by more than M falls back to the gathers, so M only moves time.
+    int min_rows_work = 8192;    // rows*pairs of a level below which the tile kernels are used (measured at 512^2 with k_iter2_tile: 16 pairs
+                                 // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
+    int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
+    int lag = DEFAULT_LAG;
+    int slots_override = 0;      // resident blocks the strips are sized for (0 = what the occupancy query says)
+    int coop_test_occ16 = -1, coop_test_occ8 = -1;   // tests: pretend the occupancy query answered this
+    int coop_test_mute = 0;      // tests: block 0 of every co-resident launch never raises its flag -> its neighbours give up -> the call is repeated tiled
+    int profile = 0;
+};
+
+struct tf_handle : TfKnobs {
     tf_params P;
     int dev = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    int profile = 0;
     std::string err;
     // geometry the buffers are allocated for
     int H = 0, W = 0, cap = 0, nlev = 0;
@@ -97,81 +157,69 @@ struct tf_handle {
     DfBufs df = {};
     // ---- analysis session (row f1) ----
     double* an_rad = nullptr; double* an_lon = nullptr; int anN = 0, anH = 0, anW = 0;
-    // tuning knobs (tf_set_tuning)
-    int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
-                                 // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
-    int force_ry = 0;            // 0 = floor(256/QX) rows per step
-    int iter_wave = 0;           // 1: batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
-                                 // instead of k_iter2_rows; 0 = never
-    int wave_max_w = 512;        // widest level the one-wave-per-strip kernels take (<= 512)
-    int wave_minrows = 8;        // k_iter2_wave: shortest strip (rows)
-    int wave_px = 0;             // k_iter2_wave: pixels per lane (4 / 6 / 8); 0 = the narrowest form that covers the level's width
-    int iter_k3 = 0;             // 1: THREE iterations per launch (k_iter3_wave) wherever k_iter2_wave applies and inner_iterations is a multiple of 3
-    int wave_pf = 0;             // k_iter2_wave: 1 = one wave per SIMD with the next row's loads in flight (three register sets), 0 = two or three waves per SIMD
-    int wave_slots = 0;          // k_iter2_wave: resident waves to size the strips for (0 = what the occupancy query says)
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
                                  // while one lane runs the thin tail of a stage, the other fills the GPU.  Measured at 128 pairs
                                  // @512^2: 1 lane 2180, 2 lanes 2470, 3 lanes 2415, 4 lanes 2165 pairs/s (DeepFlow 377 vs 309)
     std::vector<tf_handle*> twins; bool is_twin = false;   // extra lanes (own stream, buffers, host thread each)
-    int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
-    int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
-    int slots_override = 0, num_cus = 256;
-    int tile_max_w = 0;          // levels this narrow or narrower always take the tile kernels (experiment: see DESIGN section 8)
-    int tile2 = 1;               // launches the row strips do not take (single pair, few pairs, > 2048 px wide) run two iterations per launch on tiles
-    int max_strip_width = 2048;  // widest level the full-width strip kernels take (one quad per thread: 2048 px = 512-thread blocks).
-                                 // 8 pairs: 1080x1920 57.7 vs 32.6 pairs/s with the tile kernel, 768x1100 184 vs 131, 720x1280 137 vs 148
-    int sub_batches = 1;         // >1 cuts a host-pointer call that fits the capacity into that many sub-batches so the copy-out of
-                                 // one overlaps the solve of the next; measured at 128 pairs @512^2: smaller batches cost more (2099 /
-                                 // 2030 / 1886 / 1701 pairs/s for 1 / 2 / 3 / 4) than the 5 ms of D2H they hide.  Calls larger than
-                                 // the capacity are cut anyway and do overlap.
+    int num_cus = 256;
     // WASE scratch (grown on demand): compacted products, block counts / offsets, piece sums, per-flow backgrounds
     float* wa = nullptr; size_t wa_cap = 0;
     unsigned* wcnt = nullptr; u64* woff = nullptr; size_t wcnt_cap = 0;
     float* wsum = nullptr; size_t wsum_cap = 0;
     float* wbg = nullptr; size_t wbg_cap = 0;
     std::map<size_t, int> slots_cache;      // resident k_iter2_rows blocks on the device, by (LDS bytes, waves per block)
-    int sor_rt = 1;              // DeepFlow SOR: 1 = register-tile kernel k_df_sor_rt (teeflow_sor_rt.hip.h), 0 = one colour per launch (k_df_sor)
-    int sor_plain_div = 0;       // tests: k_df_sor_rt takes its plain-IEEE-division path (what a block with out-of-range diagonals does)
-    int sor_rt_shape = 3;        // k_df_sor_rt: 1 = 16 bands x 4 rows (1024 threads), 2 = 8 bands x 4 rows (128 x 32
-                                 // regions, 512 threads), 3 = 1 or 2 per launch (launch_sor_rt)
-    int df_fuse_ds = 2;          // DeepFlow: data term + smoothness contributions in one kernel (non-zero: k_df_data_smooth4, four pixels per thread,
-                                 // 16-byte loads; 0: k_df_data then k_df_smooth, the plain form it is tested against)
-    int sor_coop = 1;            // DeepFlow: all sweeps of a fixed-point iteration in one launch of co-resident regions (k_df_sor_rt_coop) where a
-                                 // level needs more than one region and its regions fit the CUs this handle may use; 0 = always the tiled form,
-                                 // 2 = 128 x 64 regions whatever the batch size and however full the launches (tests), 3 = the small-batch form
-                                 // (128 x 32 regions) whenever the batch is small, sor_coop_small or not (tests)
-    int sor_coop_min_util = 85;  // co-resident launches must be at least this full (per cent) RELATIVE to the tiled form's rounds, else the level runs
-                                 // tiled (600x800 studies: 324 pairs/s always co-resident, 357 tiled, 359 with the rule)
-    int sor_coop_small = 1;      // few pairs: co-resident 128 x 32 regions (0: the tiled form, as before)
-    int sor_coop_s = 5;          // sweeps between two exchanges of (du, dv) in that kernel (the halo is 2 x this)
     int coop_share = 0;          // CUs (= resident 1024-thread blocks) this handle may fill with such a launch; set per call (calc_entry)
     bool coop_disabled = false;  // a launch of this handle gave up waiting (foreign work on the GPU): tiled form until the back-off has run out
     int coop_backoff = 0;        // tiled solves (sub-batches) to sit out before the co-resident form is tried again; doubles with every abort
     int coop_cooldown = 0;       // ... of which this many are left
     int coop_rearms = 0;         // times the form was re-armed after a back-off
     int coop_occ16 = -1, coop_occ8 = -1;   // resident blocks per CU of k_df_sor_rt_coop<4,16> / <4,8> (hipOccupancyMaxActiveBlocksPerMultiprocessor), -1 = not asked yet
+    int coop_asked16 = -2, coop_asked8 = -2;   // the test overrides (knobs) that answer was made with
     bool coop_used = false;      // this call launched k_df_sor_rt_coop
     int coop_aborts = 0;
-    int coop_test_occ16 = -1, coop_test_occ8 = -1;   // tests: pretend the occupancy query answered this
-    int coop_test_mute = 0;      // tests: block 0 of every co-resident launch never raises its flag -> its neighbours give up -> the call is repeated tiled
     long long coop_launches = 0;
     unsigned coop_epoch = 0;     // flag value base of the next launch
     unsigned* coop_flags = nullptr;   // one 128-byte line per resident block + the abort word behind them
     int coop_flag_lines = 0;
-    int sor_fuse = 5;            // DeepFlow: complete red-black SOR sweeps per launch of k_df_sor_rt (0 = one colour per launch, in place).
-                                 // 64 pairs @512^2: 466 / 534 / 562 / 548 / 567 pairs/s for 3 / 4 / 5 / 6 / 7; 5 divides the 25 sweeps evenly
-    int warp_margin = 8;         // > 0: k_warp_lds<M> stages the I1 tile + margin in LDS (0: k_warp, 36 global gathers per pixel).  k_warp is
-                                 // bound by the texture path (~7-10 cycles per scattered dword load and wave); from LDS the same taps cost
-                                 // ~2.  128 pairs @512^2, warp stage per step: 5.0 ms gathers, 3.35 / 3.5 / 3.55 / 3.8 ms for M = 4 / 8 / 12 /
-                                 // 16 (+3.4 % pairs/s).  A pixel displaced by more than M falls back to the gathers, so M only moves time.
-    int min_rows_work = 8192;    // rows*pairs of a level below which the tile kernels are used (measured at 512^2 with k_iter2_tile: 16 pairs
-                                 // 12.5 ms on tiles vs 13.9 ms on strips, 24 pairs 17.1 vs 17.3, 64 pairs 34.1 vs 29.5)
-    int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
-    int lag = DEFAULT_LAG;
     // RCCL: one communicator rank per handle, its own stream, a small ring of completion events
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 0;
     hipStream_t comm_stream = nullptr; hipEvent_t comm_ev[8] = {}; hipEvent_t comm_ready = nullptr; unsigned comm_tickets = 0;
     double warp_ms = 0, median_ms = 0;   // profiling: summed launch durations per stage of the last call
+    // ---- engine lanes that pull whole sub-batches from a queue (calc_entry, tf_submit_*) ----
+    int queue_lanes = -1;        // -1 = per algorithm (3 DualTVL1, 1 DeepFlow); 0 = never: every call is cut in contiguous parts that are joined at its end
+    int queue_unit = 0;          // pairs per queue unit (0 = max_batch, the sub-batch size)
+    int queue_test_fail_unit = -1;   // tests: the lane that takes this unit of the next queued job reports a failure instead of solving it
+    bool is_lane = false;        // this handle is a queue lane of another handle (an engine of its own: stream, buffers, host thread, its own twins)
+    LanePool* pool = nullptr;
+    long long q_jobs = 0, q_units_done = 0, q_units_skipped = 0;
+    std::map<int, QJob*> tickets; int next_ticket = 1;      // tf_submit_* jobs not yet waited for
+};
+
+
+// ---- lanes that pull whole sub-batches from a queue ---------------------------------------------------------------------------
+// A call larger than one sub-batch (and every tf_submit_* job) becomes a QJob: it is cut into units of at most `unit` pairs, and the
+// handle's lanes -- engines of their own: handle, stream, buffers, host thread -- take one unit at a time, oldest job first.  A lane
+// that has finished a unit starts the next one at once, whichever job it belongs to, so one sub-batch's tail (few pairs still
+// iterating, the fine pyramid levels done) runs under other sub-batches' full launches.  Rounds 1-4 cut such a call into L contiguous
+// parts and joined them; bench.py reached the same overlap with three engines driven by Python threads (EnginePool).
+struct QJob {
+    int mode = 0; const uint8_t* in0 = nullptr; const uint8_t* in1 = nullptr; int n_pairs = 0, H = 0, W = 0; float scale = 1.f;
+    float* out = nullptr; bool device = false; int src_f32 = 0;
+    tf_params P; tf_deepflow_params DP; TfKnobs knobs;      // the engine's settings when the job was queued
+    int split_lanes = 1;                                    // lanes each unit is split over inside its queue lane (calc_split)
+    int unit = 0, n_units = 0, next = 0, done = 0, fail_unit = -1;
+    int rc = TF_OK; std::string err;
+    tf_stats st; int merged = 0;
+    std::vector<int> iters; size_t per_pair = 0; int nlev = 0, warps = 0;
+    double t0 = 0;
+    std::function<void(QJob*)> on_done;                     // run once, by the lane that finishes the last unit, before `finished`
+    bool finished = false;
+};
+struct LanePool {
+    std::mutex m; std::condition_variable cv_work, cv_done;
+    std::deque<QJob*> jobs;                                 // jobs that still have units to hand out, oldest first
+    std::vector<tf_handle*> lanes; std::vector<std::thread> th;
+    bool stop = false; int outstanding = 0;                 // jobs queued and not finished
 };
 
 TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out);
@@ -368,6 +416,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
         hipLaunchKernelGGL(k_iter2_tile, dim3((g.w + T2_OW - 1) / T2_OW, (g.h + T2_OH - 1) / T2_OH, B), dim3(256), 0, s, A);
         return;
     }
+#ifdef TF_EXPERIMENTAL
     if (h->iter_wave && g.w <= h->wave_max_w && B <= 1024) {
         // one wave per strip: PX pixels per lane (float4 / float2 loads need PX*lanes to stay inside the padded row)
         const int px = wave_px(h, g);
@@ -396,6 +445,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
         hipLaunchKernelGGL(kern, dim3(items), dim3(64), 0, s, A, slots, h->wave_minrows);
         return;
     }
+#endif
     int R, QX, RY, threads;
     // rows per strip follow the number of pairs known to be still iterating: the thin tail launches of a stage get many
     // short strips (latency of a few steps) instead of a few long ones
@@ -427,6 +477,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
 }
 
+#ifdef TF_EXPERIMENTAL
 // three iterations per launch: does this stage qualify?  (levels up to 512 px wide, a batch worth the strips, inner % 3 == 0 so that
 // the median cadence stays on a pass boundary, the CPU variant's stop rule)
 bool three_ok(const tf_handle* h, const Geom& g, int B, int inner)
@@ -459,6 +510,10 @@ void launch_iter3(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
     }
     hipLaunchKernelGGL(kern, dim3(items), dim3(64), 0, s, A, slots, h->wave_minrows);
 }
+
+#else
+inline bool three_ok(const tf_handle*, const Geom&, int, int) { return false; }
+#endif
 
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
 void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
@@ -543,6 +598,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
+#ifdef TF_EXPERIMENTAL
     if (!cuda_variant && three_ok(h, g, B, inner)) {
         // three iterations per launch; pass index it = 0,3,..,total (the last one can only hold REPLAY strips)
         int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
@@ -591,6 +647,7 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
                            total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
         return TF_OK;
     }
+#endif
     const bool two = cuda_variant || (h->iter_variant >= 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
@@ -802,7 +859,8 @@ void coop_tick(tf_handle* h)
 // instead of assuming it: a build whose register or LDS use has grown past that is refused the form (the tiled one does the same work).
 void coop_query_occupancy(tf_handle* h)
 {
-    if (h->coop_occ16 >= 0) return;
+    if (h->coop_occ16 >= 0 && h->coop_asked16 == h->coop_test_occ16 && h->coop_asked8 == h->coop_test_occ8) return;
+    h->coop_asked16 = h->coop_test_occ16; h->coop_asked8 = h->coop_test_occ8;
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_df_sor_rt_coop<4, 16>, 1024, 0) != hipSuccess) a = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_df_sor_rt_coop<4, 8>, 512, 0) != hipSuccess) b = 0;
@@ -1240,8 +1298,20 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     return TF_OK;
 }
 
-// Entry used by the C ABI: optionally splits the batch over several lanes (this handle + twins with their own stream,
-// buffers and host thread): the launch gaps and thin tail launches of one lane are filled by the others.
+void merge_stats(tf_stats* st, const tf_stats& sb)
+{
+    st->ms_total = std::max(st->ms_total, sb.ms_total);
+    st->ms_h2d = std::max(st->ms_h2d, sb.ms_h2d);
+    st->ms_device = std::max(st->ms_device, sb.ms_device);
+    st->ms_d2h = std::max(st->ms_d2h, sb.ms_d2h);
+    st->iter_launches += sb.iter_launches; st->iter_pair_steps += sb.iter_pair_steps; st->iter_ms += sb.iter_ms;
+    st->iter_bytes += sb.iter_bytes; st->total_bytes += sb.total_bytes;
+    st->ms_warp += sb.ms_warp; st->ms_median += sb.ms_median; st->ms_misc += sb.ms_misc; st->ms_sched += sb.ms_sched;
+    st->inner_iters_total += sb.inner_iters_total; st->outer_iters_total += sb.outer_iters_total;
+}
+
+// One sub-batch-sized call: optionally split over several lanes (this handle + twins with their own stream, buffers and host
+// thread, joined at the end): the launch gaps and thin tail launches of one lane are filled by the others.
 // Whatever went wrong, nothing of the failed call may still be in flight when the caller gets its buffers back (a D2H
 // copy into flow_out on the copy stream, kernels writing the caller's device buffer): drain every stream of the handle.
 int calc_common_guarded(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
@@ -1256,7 +1326,7 @@ int calc_common_guarded(tf_handle* h, Mode mode, const uint8_t* in0, const uint8
     return rc;
 }
 
-int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
+int calc_split(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
                float* flow_out, bool device, tf_stats* st)
 {
     if (!h) return TF_ERR_INVALID_ARG;
@@ -1280,13 +1350,10 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     std::vector<std::thread> th;
     for (int k = 1; k < L; ++k) {
         tf_handle* t = h->twins[k - 1];
-        t->P = h->P; t->DP = h->DP; t->profile = h->profile; t->src_f32 = h->src_f32;
-        t->sor_coop = h->sor_coop; t->sor_coop_s = h->sor_coop_s; t->sor_coop_small = h->sor_coop_small; t->sor_coop_min_util = h->sor_coop_min_util; t->coop_test_mute = h->coop_test_mute; if (t->coop_test_occ16 != h->coop_test_occ16 || t->coop_test_occ8 != h->coop_test_occ8) { t->coop_test_occ16 = h->coop_test_occ16; t->coop_test_occ8 = h->coop_test_occ8; t->coop_occ16 = -1; coop_query_occupancy(t); } t->coop_share = (claim.ok ? h->num_cus : 0) / L;
-        t->iter_variant = h->iter_variant; t->strip_blocks = h->strip_blocks; t->lag = h->lag; t->force_ry = h->force_ry;
-        t->iter_wave = h->iter_wave; t->wave_minrows = h->wave_minrows; t->wave_px = h->wave_px; t->wave_max_w = h->wave_max_w; t->wave_slots = h->wave_slots; t->wave_pf = h->wave_pf; t->iter_k3 = h->iter_k3;
-        t->min_rows_work = h->min_rows_work; t->warp_margin = h->warp_margin; t->sor_fuse = h->sor_fuse; t->df_fuse_ds = h->df_fuse_ds;
-        t->dynamic_strips = h->dynamic_strips; t->slots_override = h->slots_override; t->adaptive_strips = h->adaptive_strips;
-        t->sub_batches = h->sub_batches; t->max_strip_width = h->max_strip_width; t->tile2 = h->tile2; t->sor_rt = h->sor_rt; t->sor_rt_shape = h->sor_rt_shape; t->sor_plain_div = h->sor_plain_div; t->tile_max_w = h->tile_max_w;
+        t->P = h->P; t->DP = h->DP; t->src_f32 = h->src_f32;
+        static_cast<TfKnobs&>(*t) = static_cast<const TfKnobs&>(*h);          // every knob, one assignment
+        if (t->coop_flags) coop_query_occupancy(t);                           // asks again only if the test overrides have changed
+        t->coop_share = (claim.ok ? h->num_cus : 0) / L;
         // pairs [first[k], first[k+1]); in sequence mode the lane's frames start at its first pair (one frame of overlap)
         const uint8_t* b0 = in0 + (size_t)first[k] * fpx;
         const uint8_t* b1 = mode == MODE_SEQ ? nullptr : in1 + (size_t)first[k] * fpx;
@@ -1305,21 +1372,218 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     if (st) {
         *st = ss[0];
         st->n_pairs = n_pairs;
-        for (int k = 1; k < L; ++k) {
-            const tf_stats& sb = ss[k];
-            st->ms_total = std::max(st->ms_total, sb.ms_total);
-            st->ms_h2d = std::max(st->ms_h2d, sb.ms_h2d);
-            st->ms_device = std::max(st->ms_device, sb.ms_device);
-            st->ms_d2h = std::max(st->ms_d2h, sb.ms_d2h);
-            st->iter_launches += sb.iter_launches; st->iter_pair_steps += sb.iter_pair_steps; st->iter_ms += sb.iter_ms;
-            st->iter_bytes += sb.iter_bytes; st->total_bytes += sb.total_bytes;
-            st->ms_warp += sb.ms_warp; st->ms_median += sb.ms_median; st->ms_misc += sb.ms_misc; st->ms_sched += sb.ms_sched;
-            st->inner_iters_total += sb.inner_iters_total; st->outer_iters_total += sb.outer_iters_total;
-        }
+        for (int k = 1; k < L; ++k) merge_stats(st, ss[k]);
     }
     return TF_OK;
 }
 
+
+// ---- the queue (structs above tf_create's prototype) ---------------------------------------------------------------------------
+int queue_lane_count(const tf_handle* h)
+{
+    if (h->queue_lanes >= 0) return h->queue_lanes > 8 ? 8 : h->queue_lanes;
+    return h->P.algo == TF_ALGO_DEEPFLOW ? 1 : 3;           // DeepFlow's co-resident SOR launches take every CU: one lane (its units are split over two twins)
+}
+int queue_unit_pairs(const tf_handle* h)
+{
+    const int mb = h->P.algo == TF_ALGO_DEEPFLOW ? h->DP.max_batch : h->P.max_batch;
+    const int cap = mb > 0 ? mb : DEFAULT_MAX_BATCH;
+    return h->queue_unit > 0 && h->queue_unit < cap ? h->queue_unit : cap;
+}
+
+void lane_worker(tf_handle* owner, LanePool* pool, tf_handle* lane)
+{
+    for (;;) {
+        QJob* j; int u; bool skip;
+        {
+            std::unique_lock<std::mutex> lk(pool->m);
+            pool->cv_work.wait(lk, [&] { return pool->stop || !pool->jobs.empty(); });
+            if (pool->jobs.empty()) return;                  // stop was asked for and nothing is left to hand out
+            j = pool->jobs.front();
+            u = j->next++;
+            if (j->next >= j->n_units) pool->jobs.pop_front();
+            skip = j->rc != TF_OK;                           // a unit of this job has failed: the rest is not started
+        }
+        tf_stats us; memset(&us, 0, sizeof us);
+        int rc = TF_OK;
+        const int c0 = u * j->unit, nb = j->n_pairs - c0 < j->unit ? j->n_pairs - c0 : j->unit;
+        if (!skip) {
+            const size_t npx = (size_t)j->H * j->W, fpx = npx * (j->src_f32 ? 4 : 1);
+            lane->P = j->P; lane->DP = j->DP; lane->src_f32 = j->src_f32; lane->lanes = j->split_lanes;
+            static_cast<TfKnobs&>(*lane) = j->knobs;
+            if (lane->coop_flags) coop_query_occupancy(lane);        // asks again only if the test overrides have changed
+            if (u == j->fail_unit) rc = fail(lane, TF_ERR_HIP, "injected failure (queue_test_fail_unit)");
+            else rc = calc_split(lane, (Mode)j->mode, j->in0 + (size_t)c0 * fpx, j->in1 ? j->in1 + (size_t)c0 * fpx : nullptr, nb, j->H, j->W, j->scale,
+                                 j->out + (size_t)c0 * npx * 2, j->device, &us);
+            lane->src_f32 = 0;
+        }
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(pool->m);
+            if (skip) ++owner->q_units_skipped; else ++owner->q_units_done;
+            if (!skip && rc != TF_OK) {
+                if (j->rc == TF_OK) {
+                    j->rc = rc;
+                    char where[96]; snprintf(where, sizeof where, "sub-batch %d (pairs %d..%d): ", u, c0, c0 + nb - 1);
+                    j->err = std::string(where) + lane->err;
+                }
+            } else if (!skip) {
+                if (!j->merged++) { const double t = j->st.ms_total; j->st = us; j->st.ms_total = t; } else merge_stats(&j->st, us);
+                if (j->per_pair && lane->last_iters.size() == (size_t)nb * j->per_pair)
+                    memcpy(j->iters.data() + (size_t)c0 * j->per_pair, lane->last_iters.data(), (size_t)nb * j->per_pair * sizeof(int));
+            }
+            last = ++j->done == j->n_units;
+        }
+        if (last) {
+            // every lane that worked for this job has drained its streams (a solve is host-synchronous, a failed one drains in
+            // calc_common_guarded): nothing of the job is in flight any more
+            if (j->on_done) j->on_done(j);
+            std::lock_guard<std::mutex> lk(pool->m);
+            j->finished = true;
+            --pool->outstanding;
+            pool->cv_done.notify_all();                      // (the waiter may free the job from here on)
+        }
+    }
+}
+
+void pool_destroy(tf_handle* h)
+{
+    LanePool* pool = h->pool;
+    if (!pool) return;
+    {
+        std::lock_guard<std::mutex> lk(pool->m);
+        pool->stop = true;                                   // the lanes first finish what is queued
+    }
+    pool->cv_work.notify_all();
+    for (auto& t : pool->th) t.join();
+    for (tf_handle* l : pool->lanes) tf_destroy(l);
+    delete pool;
+    h->pool = nullptr;
+}
+
+// the handle's lanes, made on first use (and again when the "queue_lanes" knob has changed and nothing is queued)
+int pool_ensure(tf_handle* h)
+{
+    const int want = queue_lane_count(h);
+    if (h->pool && (int)h->pool->lanes.size() != want) {
+        bool idle;
+        { std::lock_guard<std::mutex> lk(h->pool->m); idle = h->pool->outstanding == 0; }
+        if (idle) pool_destroy(h);
+    }
+    if (h->pool) return TF_OK;
+    LanePool* pool = new LanePool();
+    for (int k = 0; k < want; ++k) {
+        tf_handle* t = nullptr;
+        const int rc = h->P.algo == TF_ALGO_DEEPFLOW ? tf_create_deepflow(&h->DP, h->dev, &t) : tf_create(&h->P, h->dev, &t);
+        if (rc) {
+            for (tf_handle* l : pool->lanes) tf_destroy(l);
+            delete pool;
+            return fail(h, rc, "creating queue lane %d failed: %s", k + 1, tf_last_error(nullptr));
+        }
+        t->is_lane = true;
+        pool->lanes.push_back(t);
+    }
+    h->pool = pool;
+    for (tf_handle* l : pool->lanes) pool->th.emplace_back(lane_worker, h, pool, l);
+    return TF_OK;
+}
+
+// fills the job from the handle's current settings and hands it to the lanes
+int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, bool device)
+{
+    const bool deep = h->P.algo == TF_ALGO_DEEPFLOW;
+    int rc = deep ? df_validate(h, h->DP) : validate_params(h, h->P);
+    if (rc) return rc;
+    if ((long long)H * W > (1LL << 24)) return fail(h, TF_ERR_UNSUPPORTED, "images above 2^24 pixels are not supported");
+    if (deep && h->src_f32) return fail(h, TF_ERR_UNSUPPORTED, "float32 frames are supported by the DualTVL1 engine only");
+    rc = pool_ensure(h);
+    if (rc) return rc;
+    j->mode = mode; j->in0 = in0; j->in1 = in1; j->n_pairs = n_pairs; j->H = H; j->W = W; j->scale = scale; j->out = flow_out; j->device = device;
+    j->src_f32 = h->src_f32; j->P = h->P; j->DP = h->DP; j->knobs = static_cast<const TfKnobs&>(*h);
+    j->split_lanes = deep ? h->lanes : 1;
+    j->unit = queue_unit_pairs(h);
+    j->n_units = (n_pairs + j->unit - 1) / j->unit;
+    j->fail_unit = h->queue_test_fail_unit; h->queue_test_fail_unit = -1;
+    memset(&j->st, 0, sizeof j->st);
+    if (deep) {
+        std::vector<Geom> lv(DF_MAXLEV);
+        j->nlev = df_levels(h->DP, H, W, lv.data()); j->warps = 0; j->per_pair = 0;
+    } else {
+        Geom lv[MAXLEV];
+        j->nlev = compute_levels(h->P, H, W, lv); j->warps = h->P.warps; j->per_pair = (size_t)j->nlev * j->warps * 2;
+    }
+    j->iters.assign((size_t)n_pairs * j->per_pair, 0);
+    j->t0 = now_ms();
+    {
+        std::lock_guard<std::mutex> lk(h->pool->m);
+        h->pool->jobs.push_back(j);
+        ++h->pool->outstanding;
+        ++h->q_jobs;
+    }
+    h->pool->cv_work.notify_all();
+    return TF_OK;
+}
+
+// waits for the job and moves its results to where a synchronous call leaves them (tf_get_iters, tf_last_error, *st)
+int queue_finish(tf_handle* h, QJob* j, tf_stats* st)
+{
+    if (h->pool) {
+        std::unique_lock<std::mutex> lk(h->pool->m);
+        h->pool->cv_done.wait(lk, [&] { return j->finished; });
+    }
+    h->last_iters = std::move(j->iters);
+    h->last_pairs = j->n_pairs; h->last_nlev = j->nlev; h->last_warps = j->warps;
+    if (j->rc != TF_OK) { h->err = j->err; return j->rc; }
+    if (st) {
+        *st = j->st;
+        st->n_pairs = j->n_pairs; st->nscales_used = j->nlev; st->warps = j->warps;
+        st->ms_total = now_ms() - j->t0;
+    }
+    return TF_OK;
+}
+
+// Entry used by the C ABI.  A call of at most one sub-batch is solved by this handle (calc_split: contiguous parts on its twins,
+// joined).  A larger one -- or any call while tf_submit_* jobs are in flight -- goes to the queue: whole sub-batches, taken by the
+// lanes as they come free; the call returns when every lane has finished its last unit of it (a failed unit stops the job's
+// remaining units from starting; the units already running complete, so nothing of the call is in flight when it returns).
+int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
+               float* flow_out, bool device, tf_stats* st)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    const bool can_queue = !h->is_twin && !h->is_lane && queue_lane_count(h) > 0 && in0 && flow_out && (mode != MODE_PAIRS || in1) && H >= 1 && W >= 1 &&
+                           n_pairs >= 1 && h->stream == h->own_stream;
+    bool busy = false;
+    if (can_queue && h->pool) { std::lock_guard<std::mutex> lk(h->pool->m); busy = h->pool->outstanding > 0; }
+    if (!can_queue || (!busy && n_pairs <= queue_unit_pairs(h)))
+        return calc_split(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
+    QJob j;
+    int rc = queue_submit(h, &j, mode, in0, in1, n_pairs, H, W, scale, flow_out, device);
+    if (rc) return rc;
+    return queue_finish(h, &j, st);
+}
+
+// tf_submit_*: the same job, not waited for.  Returns a ticket for tf_wait.
+int submit_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, bool device, int* ticket)
+{
+    if (!h || !ticket) return TF_ERR_INVALID_ARG;
+    if (!in0 || (mode == MODE_PAIRS && !in1) || !flow_out) return fail(h, TF_ERR_INVALID_ARG, "null image/flow pointer");
+    if (H < 1 || W < 1 || n_pairs < 1) return fail(h, TF_ERR_INVALID_ARG, "bad sizes: pairs=%d H=%d W=%d", n_pairs, H, W);
+    if (h->is_twin || h->is_lane || h->stream != h->own_stream) return fail(h, TF_ERR_UNSUPPORTED, "tf_submit_* needs the handle's own stream");
+    QJob* j = new QJob();
+    int rc;
+    if (queue_lane_count(h) < 1) {                           // "queue_lanes" = 0: no lanes, the job is done when the call returns
+        tf_stats st;
+        rc = calc_split(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, &st);
+        if (rc) { delete j; return rc; }
+        j->st = st; j->n_pairs = n_pairs; j->nlev = h->last_nlev; j->warps = h->last_warps; j->iters = h->last_iters; j->t0 = now_ms() - st.ms_total; j->finished = true;
+    } else {
+        rc = queue_submit(h, j, mode, in0, in1, n_pairs, H, W, scale, flow_out, device);
+        if (rc) { delete j; return rc; }
+    }
+    *ticket = h->next_ticket++;
+    h->tickets[*ticket] = j;
+    return TF_OK;
+}
 // ---- small RAII device buffer for the tf_dbg_* hooks ---------------------------------------------
 struct DBuf {
     float* p = nullptr;
@@ -1449,6 +1713,9 @@ TF_API int tf_create(const tf_params* p, int device_id, tf_handle** out)
 TF_API void tf_destroy(tf_handle* h)
 {
     if (!h) return;
+    pool_destroy(h);                                     // the lanes finish what is queued, then go
+    for (auto& kv : h->tickets) delete kv.second;
+    h->tickets.clear();
     for (tf_handle* t : h->twins) tf_destroy(t);
     h->twins.clear();
     (void)hipSetDevice(h->dev);
@@ -1530,6 +1797,10 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
 {
     if (!h || !name) return TF_ERR_INVALID_ARG;
     const std::string n(name);
+#ifndef TF_EXPERIMENTAL
+    if ((n == "iter_variant" && value >= 4) || ((n == "iter_wave" || n == "wave_pf") && value != 0))
+        return fail(h, TF_ERR_UNSUPPORTED, "%s=%d names a one-wave-per-strip form of tvl1_iter: experiments, built only with `make EXPERIMENTAL=1` (DESIGN.md section 4c)", name, value);
+#endif
     if (n == "iter_variant") {                      // 4 / 5 / 6 = one wave per strip where it applies (4: two or three waves per SIMD; 5: one wave per SIMD
         h->iter_wave = value >= 4 ? 1 : 0;          // with the next row's loads in flight; 6: that with THREE iterations per launch where inner % 3 == 0);
         if (value >= 4) h->wave_pf = value >= 5 ? 1 : 0;   // 0 / 1 / 2 name one of the older forms explicitly
@@ -1557,10 +1828,18 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "max_strip_width") h->max_strip_width = value < 4 ? 4 : (value > 2048 ? 2048 : value);
     else if (n == "sub_batches") h->sub_batches = value < 1 ? 1 : value;
     else if (n == "lanes") h->lanes = value < 1 ? 1 : (value > 8 ? 8 : value);
+    else if (n == "queue_lanes") h->queue_lanes = value;          // -1 = per algorithm (3 DualTVL1, 1 DeepFlow), 0 = no queue: contiguous parts, joined
+    else if (n == "queue_unit") h->queue_unit = value < 0 ? 0 : value;
+    else if (n == "queue_test_fail_unit") h->queue_test_fail_unit = value;
     else if (n == "sor_fuse") h->sor_fuse = value;
     else if (n == "sor_coop") {                       // setting the knob re-arms the form at once and forgets the back-off
         h->sor_coop = value;
-        if (value) { h->coop_disabled = false; h->coop_backoff = h->coop_cooldown = 0; for (auto* t : h->twins) { t->coop_disabled = false; t->coop_backoff = t->coop_cooldown = 0; } }
+        if (value) {
+            std::vector<tf_handle*> all{h};
+            for (auto* t : h->twins) all.push_back(t);
+            if (h->pool) for (auto* l : h->pool->lanes) { all.push_back(l); for (auto* t : l->twins) all.push_back(t); }
+            for (auto* t : all) { t->coop_disabled = false; t->coop_backoff = t->coop_cooldown = 0; }
+        }
     }
     else if (n == "sor_coop_s") h->sor_coop_s = value;
     else if (n == "sor_coop_small") h->sor_coop_small = value ? 1 : 0;
@@ -1596,11 +1875,29 @@ TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
     if (!h || !name) return -1;
     const std::string n(name);
     long long v = -1;
-    if (n == "coop_launches") { v = h->coop_launches; for (auto* t : h->twins) v += t->coop_launches; }
-    else if (n == "coop_aborts") { v = h->coop_aborts; for (auto* t : h->twins) v += t->coop_aborts; }
-    else if (n == "coop_disabled") { v = h->coop_disabled; for (auto* t : h->twins) v |= (long long)t->coop_disabled; }
-    else if (n == "coop_rearms") { v = h->coop_rearms; for (auto* t : h->twins) v += t->coop_rearms; }
-    else if (n == "coop_cooldown") { v = h->coop_cooldown; for (auto* t : h->twins) v = v > t->coop_cooldown ? v : t->coop_cooldown; }
+    std::vector<tf_handle*> all{h};                              // this handle, its twins, its queue lanes and theirs
+    for (auto* t : h->twins) all.push_back(t);
+    if (h->pool) for (auto* l : h->pool->lanes) { all.push_back(l); for (auto* t : l->twins) all.push_back(t); }
+    if (n == "coop_launches") { v = 0; for (auto* t : all) v += t->coop_launches; }
+    else if (n == "coop_aborts") { v = 0; for (auto* t : all) v += t->coop_aborts; }
+    else if (n == "coop_disabled") { v = 0; for (auto* t : all) v |= (long long)t->coop_disabled; }
+    else if (n == "coop_rearms") { v = 0; for (auto* t : all) v += t->coop_rearms; }
+    else if (n == "coop_cooldown") { v = 0; for (auto* t : all) v = v > t->coop_cooldown ? v : t->coop_cooldown; }
+    else if (n == "queue_jobs") v = h->q_jobs;
+    else if (n == "queue_units_done" || n == "queue_units_skipped" || n == "queue_outstanding" || n == "queue_lanes") {
+        v = 0;
+        if (h->pool) {
+            std::lock_guard<std::mutex> lk(h->pool->m);
+            v = n == "queue_units_done" ? h->q_units_done : n == "queue_units_skipped" ? h->q_units_skipped : n == "queue_outstanding" ? h->pool->outstanding : (long long)h->pool->lanes.size();
+        }
+    }
+    else if (n == "experimental") {
+#ifdef TF_EXPERIMENTAL
+        v = 1;
+#else
+        v = 0;
+#endif
+    }
     else if (n == "coop_occ16") v = h->coop_occ16;
     else if (n == "coop_occ8") v = h->coop_occ8;
     return v;
@@ -1682,6 +1979,48 @@ TF_API int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H
 {
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
     return calc_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, st);
+}
+
+// ---- asynchronous forms: the job is queued on the handle's lanes and the call returns; tf_wait collects it ----------------------
+TF_API int tf_submit_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W, float scale, float* dflow_out, int* ticket)
+{
+    return submit_entry(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, true, ticket);
+}
+TF_API int tf_submit_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, int* ticket)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    return submit_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, ticket);
+}
+TF_API int tf_submit_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, int* ticket)
+{
+    return submit_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, ticket);
+}
+TF_API int tf_submit_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, int* ticket)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    return submit_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, false, ticket);
+}
+TF_API int tf_wait(tf_handle* h, int ticket, tf_stats* st)
+{
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (ticket < 0) {                                        // every job not yet waited for, oldest first; the first failure is returned
+        int rc_all = TF_OK; std::string err_all;
+        while (!h->tickets.empty()) {
+            const int rc = tf_wait(h, h->tickets.begin()->first, st);
+            if (rc && !rc_all) { rc_all = rc; err_all = h->err; }
+        }
+        if (rc_all) h->err = err_all;
+        return rc_all;
+    }
+    auto f = h->tickets.find(ticket);
+    if (f == h->tickets.end()) return fail(h, TF_ERR_INVALID_ARG, "unknown ticket %d (already waited for?)", ticket);
+    QJob* j = f->second;
+    h->tickets.erase(f);
+    const int rc = queue_finish(h, j, st);
+    delete j;
+    return rc;
 }
 
 namespace {
@@ -2398,6 +2737,7 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
     const bool two = h->iter_variant == 2 && (rows_ok(h, g, 1) || h->tile2) && nsteps % 2 == 0;
     int launches = 0;
+#ifdef TF_EXPERIMENTAL
     if (three_ok(h, g, 1, 3) && nsteps % 3 == 0 && nsteps > 0) {
         for (int it = 0; it < nsteps; it += 3, ++launches) {
             Iter2Args A3;
@@ -2405,7 +2745,9 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
             A3.utog_prev = A3.ptog_prev = A3.pzero_prev = 0; A3.total = nsteps;
             launch_iter3(h, A3, 1, h->stream);
         }
-    } else if (two) {
+    } else
+#endif
+    if (two) {
         for (int it = 0; it < nsteps; it += 2, ++launches) {
             Iter2Args A2;
             A2.a = ia; A2.a.it = it; A2.a.utog = launches; A2.a.ptog = launches; A2.a.pzero = (p_is_zero && it == 0) ? 1 : 0;

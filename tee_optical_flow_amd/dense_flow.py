@@ -82,6 +82,7 @@ class DenseFlow:
     def __init__(self, device_id=0, max_batch=128, algo="TVL1", **params):
         self._L = _lib.load()
         self._pool = _PinnedPool(self._L)
+        self._jobs = {}                                    # ticket -> what a submitted job reads and writes (kept alive until wait)
         self.algo = algo
         if algo == "deepflow":
             dp = _lib.TfDeepflowParams()
@@ -122,8 +123,9 @@ class DenseFlow:
         if getattr(self, "_pool", None):
             self._pool.close()
         if getattr(self, "_h", None):
-            self._L.tf_destroy(self._h)
+            self._L.tf_destroy(self._h)                    # jobs still queued are finished first
             self._h = None
+        self._jobs = {}
 
     def _out(self, shape):
         """A fresh float32 result array (pinned host memory from the pool)."""
@@ -169,7 +171,8 @@ class DenseFlow:
         _lib.check(self._L.tf_set_tuning(self._h, name.encode(), int(value)), self._h, "tf_set_tuning")
 
     def counter(self, name):
-        """Debug counters of the engine (tf_dbg_counter): coop_launches, coop_aborts, coop_disabled, coop_rearms, coop_cooldown, coop_occ16, coop_occ8."""
+        """Debug counters of the engine (tf_dbg_counter): coop_launches, coop_aborts, coop_disabled, coop_rearms, coop_cooldown, coop_occ16, coop_occ8,
+        queue_jobs, queue_units_done, queue_units_skipped, queue_outstanding, queue_lanes, experimental."""
         return int(self._L.tf_dbg_counter(self._h, name.encode()))
 
     def _finish(self, st):
@@ -308,6 +311,53 @@ class DenseFlow:
                                                 float(scale), C.c_void_p(dflow_ptr), C.byref(st)), self._h, "tf_calc_pairs_device")
         self._finish(st)
         return self.last_stats
+
+    # ---- jobs in flight: the same calls, queued on the engine's lanes inside the library and collected later ------------------
+    def submit_pairs_device(self, dI0s_ptr, dI1s_ptr, B, H, W, dflow_ptr, scale=1.0):
+        """tf_submit_pairs_device: queue the batch on the engine's lanes and return a ticket at once; `wait(ticket)` returns its
+        statistics.  The device buffers must stay untouched until then.  Consecutive jobs overlap on the GPU (one batch's tail
+        under the next one's full launches), which a stream of synchronous calls cannot do."""
+        t = C.c_int(-1)
+        _lib.check(self._L.tf_submit_pairs_device(self._h, C.c_void_p(dI0s_ptr), C.c_void_p(dI1s_ptr), int(B), int(H), int(W), float(scale),
+                                                  C.c_void_p(dflow_ptr), C.byref(t)), self._h, "tf_submit_pairs_device")
+        self._jobs[t.value] = None
+        return t.value
+
+    def submit_batch(self, frames, scale=1.0):
+        """calc_batch without waiting: frames uint8 [N,H,W] -> ticket; `wait(ticket)` returns float32 [N-1,H,W,2]."""
+        frames = _u8_image_stack(frames, "frames", 3)
+        N, H, W = frames.shape
+        if N < 2:
+            raise OpticalFlowCalculationError("need at least 2 frames")
+        out = self._out((N - 1, H, W, 2))
+        t = C.c_int(-1)
+        _lib.check(self._L.tf_submit_seq(self._h, frames.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(t)), self._h, "tf_submit_seq")
+        self._jobs[t.value] = (out, frames)                 # the library reads `frames` and writes `out` until the wait
+        return t.value
+
+    def submit_pairs(self, I0s, I1s):
+        """calc_pairs without waiting: uint8 [B,H,W] x2 -> ticket; `wait(ticket)` returns float32 [B,H,W,2]."""
+        I0s = _u8_image_stack(I0s, "I0s", 3)
+        I1s = _u8_image_stack(I1s, "I1s", 3)
+        if I0s.shape != I1s.shape:
+            raise OpticalFlowCalculationError(f"I0s and I1s differ: {I0s.shape} vs {I1s.shape}")
+        B, H, W = I0s.shape
+        out = self._out((B, H, W, 2))
+        t = C.c_int(-1)
+        _lib.check(self._L.tf_submit_pairs(self._h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, out.ctypes.data, C.byref(t)), self._h, "tf_submit_pairs")
+        self._jobs[t.value] = (out, I0s, I1s)
+        return t.value
+
+    def wait(self, ticket):
+        """Collect a submitted job: its flows (host forms) or its statistics (device form).  `last_stats` / `last_iters()` then
+        describe that job.  A failed job raises here."""
+        if ticket not in self._jobs:
+            raise OpticalFlowCalculationError(f"unknown ticket {ticket!r} (already waited for?)")
+        keep = self._jobs.pop(ticket)
+        st = _lib.TfStats()
+        _lib.check(self._L.tf_wait(self._h, int(ticket), C.byref(st)), self._h, "tf_wait")
+        self._finish(st)
+        return keep[0] if keep is not None else self.last_stats
 
     def calc_seq_device(self, dframes_ptr, N, H, W, dflow_ptr, scale=1.0):
         st = _lib.TfStats()

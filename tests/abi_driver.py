@@ -33,6 +33,9 @@ def bind(path):
     L.tf_calc_seq.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(_lib.TfStats)]
     L.tf_calc_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.POINTER(_lib.TfStats)]
     L.tf_get_iters.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.tf_submit_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
+    L.tf_submit_seq.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(i32)]
+    L.tf_wait.argtypes = [vp, i32, C.POINTER(_lib.TfStats)]
     L.tf_last_error.argtypes = [vp]; L.tf_last_error.restype = C.c_char_p
     return L
 
@@ -74,6 +77,30 @@ def drive(L, frames, pairs):
     assert L.tf_calc_seq(h, frames.ctypes.data, N, frames.shape[1], frames.shape[2], 2.0, fs.ctypes.data, C.byref(st)) == 0   # :584-600
     out["seq_flow"] = fs
     out["seq_too_short"] = L.tf_calc_seq(h, frames.ctypes.data, 1, frames.shape[1], frames.shape[2], 1.0, fs.ctypes.data, None)
+    L.tf_destroy(h)
+    # sub-batches of 2 pairs: the 3-pair call is cut in two queue units (the product's lanes; the checker has none), then two jobs
+    # are submitted before either is waited for and collected in reverse order
+    p.max_batch = 2
+    assert L.tf_create(C.byref(p), 0, C.byref(h)) == 0
+    fq = np.empty((B, H, W, 2), np.float32)
+    assert L.tf_calc_pairs(h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, fq.ctypes.data, C.byref(st)) == 0
+    itq = np.zeros(n, np.int32)
+    assert L.tf_get_iters(h, itq.ctypes.data_as(C.c_void_p), n, C.byref(w)) == 0 and w.value == n
+    out["queued_flow"], out["queued_iters"], out["queued_stats"] = fq, itq, (st.n_pairs, st.nscales_used, st.warps, st.inner_iters_total, st.outer_iters_total)
+    fa, fb2 = np.empty((B, H, W, 2), np.float32), np.empty((N - 1,) + frames.shape[1:] + (2,), np.float32)
+    ta, tb = C.c_int(-1), C.c_int(-1)
+    assert L.tf_submit_pairs(h, I0s.ctypes.data, I1s.ctypes.data, B, H, W, fa.ctypes.data, C.byref(ta)) == 0
+    assert L.tf_submit_seq(h, frames.ctypes.data, N, frames.shape[1], frames.shape[2], 0.5, fb2.ctypes.data, C.byref(tb)) == 0
+    assert ta.value != tb.value
+    assert L.tf_wait(h, tb.value, C.byref(st)) == 0
+    out["async_seq_flow"], out["async_seq_pairs"] = fb2, st.n_pairs
+    assert L.tf_wait(h, ta.value, C.byref(st)) == 0
+    ita = np.zeros(n, np.int32)
+    assert L.tf_get_iters(h, ita.ctypes.data_as(C.c_void_p), n, C.byref(w)) == 0 and w.value == n
+    out["async_pairs_flow"], out["async_pairs_iters"] = fa, ita
+    out["wait_twice"] = L.tf_wait(h, ta.value, None)                                   # unknown ticket -> TF_ERR_INVALID_ARG
+    out["wait_all_when_none"] = L.tf_wait(h, -1, None)
+    p.max_batch = 0
     L.tf_destroy(h)
     # the CUDA-branch variant (reference :575) and DeepFlow (:568) through the same entry points
     p.variant = 1

@@ -31,6 +31,11 @@ def test_checker_library_speaks_the_abi(cpu_run, oracle):
     p = oracle.default_params(warps=3, epsilon=0.03)
     for i in range(3):
         assert np.array_equal(out["seq_flow"][i], oracle.tvl1_calc(frames[i], frames[i + 1], p) * np.float32(2.0))
+    assert np.array_equal(out["queued_flow"], out["pairs_flow"]) and np.array_equal(out["queued_iters"].reshape(out["pairs_iters"].shape), out["pairs_iters"])
+    assert np.array_equal(out["async_pairs_flow"], out["pairs_flow"]) and np.array_equal(out["async_pairs_iters"], out["queued_iters"])
+    for i in range(3):
+        assert np.array_equal(out["async_seq_flow"][i], oracle.tvl1_calc(frames[i], frames[i + 1]) * np.float32(0.5))
+    assert out["async_seq_pairs"] == 3 and out["wait_twice"] == 1 and out["wait_all_when_none"] == 0
     assert np.array_equal(out["variant_flow"], oracle.tvl1_calc(I0s[1], I1s[1], oracle.default_params(variant=1))) and out["variant_outer"] == 0
     assert np.array_equal(out["deepflow_flow"], oracle.deepflow_calc(I0s[0], I1s[0]))
 

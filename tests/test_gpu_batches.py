@@ -5,6 +5,8 @@ against the CPU oracle on a spread sample."""
 import numpy as np
 import pytest
 
+from tests.conftest import needs_experimental
+
 pytestmark = pytest.mark.gpu
 
 
@@ -148,6 +150,7 @@ def test_one_wave_per_strip_forms_in_mixed_batches(oracle, variant, n, H, W, par
     I0s, I1s = _mixed_pairs(n, H, W, seed0=700)
     eng = _engine(n, **params)
     try:
+        needs_experimental(eng, variant)
         f0, it0 = _run(eng, I0s, I1s, lanes=1)                                # default form
         eng.set_tuning("iter_variant", variant)
         eng.set_tuning("min_rows_work", 0)

@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from tests.conftest import needs_experimental
+
 pytestmark = pytest.mark.gpu
 
 
@@ -96,6 +98,7 @@ def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
     iterations per launch (variant 3 = variant 2 on a launch too small for the strips)."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
+    needs_experimental(engine, variant)
     engine.set_tuning("iter_variant", variant if variant >= 4 else min(variant, 2))
     engine.set_tuning("min_rows_work", 0 if variant != 3 else 1 << 30)   # strips even for this single small image | tiles
     try:
@@ -113,6 +116,7 @@ def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant
     the sign of zero and every denormal count)."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
+    needs_experimental(engine, variant)
     h, w = 96, 384
     rng = np.random.default_rng(21)
     k = (np.arange(w) // 8).astype(np.float64)                       # 0 .. 47

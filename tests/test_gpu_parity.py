@@ -6,6 +6,8 @@ unpinned -- cv2 is not installable here; see oracle/tvl1_oracle.c.)"""
 import numpy as np
 import pytest
 
+from tests.conftest import needs_experimental
+
 pytestmark = pytest.mark.gpu
 
 EPE_TOL_MEAN = 1e-3   # BASELINE.json north_star
@@ -111,6 +113,7 @@ def test_every_iteration_kernel_form_end_to_end(oracle, variant, params):
     from tee_optical_flow_amd.synth import speckle_pairs
     I0s, I1s = speckle_pairs(range(70, 76), 72, 88)
     eng = T.DenseFlow(**params)
+    needs_experimental(eng, variant)
     eng.set_tuning("iter_variant", variant)
     eng.set_tuning("min_rows_work", 0)
     flows = eng.calc_pairs(I0s, I1s)

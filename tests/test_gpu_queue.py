@@ -1,0 +1,171 @@
+"""The library's lane queue (calc_entry / tf_submit_* / tf_wait, include/teeflow.h "Sub-batches and lanes"): a call larger than one
+sub-batch is cut into units that the handle's lanes take one at a time.  Whatever lane solves what, flows and executed iteration
+counts are those of the contiguous-split form of rounds 1-4 (queue_lanes = 0) and of the oracle, in pair order; a failing
+sub-batch drops the ones not yet started, lets the running ones finish and leaves nothing in flight; jobs submitted without
+waiting overlap and can be collected in any order.  Reference loop: calculate_optical_flow.py:584-597 (one loop -> one call)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed(n, H, W, seed0=900):
+    from tests.test_gpu_batches import _mixed_pairs
+    return _mixed_pairs(n, H, W, seed0=seed0)
+
+
+def _engine(cap, **kw):
+    import tee_optical_flow_amd as T
+    return T.DenseFlow(device_id=0, max_batch=cap, **kw)
+
+
+@pytest.mark.parametrize("n,cap,unit", [(53, 16, 0), (48, 16, 0), (40, 16, 7), (17, 16, 0)])
+def test_queue_gives_the_split_forms_flows_and_iteration_order(oracle, n, cap, unit):
+    """3 x 16-pair sub-batches + a ragged one on three lanes (and a 7-pair unit size): np.array_equal flows, tf_get_iters in pair order."""
+    I0s, I1s = _mixed(n, 72, 96)
+    eng = _engine(cap)
+    try:
+        eng.set_tuning("queue_lanes", 0)                                  # rounds 1-4: contiguous parts, joined
+        f0 = np.array(eng.calc_pairs(I0s, I1s)); it0 = eng.last_iters().copy()
+        assert eng.counter("queue_jobs") == 0
+        eng.set_tuning("queue_lanes", -1)
+        eng.set_tuning("queue_unit", unit)
+        f1 = np.array(eng.calc_pairs(I0s, I1s)); it1 = eng.last_iters().copy()
+        u = unit or cap
+        assert eng.counter("queue_jobs") == 1 and eng.counter("queue_lanes") == 3
+        assert eng.counter("queue_units_done") == -(-n // u) and eng.counter("queue_outstanding") == 0
+        assert eng.last_stats["n_pairs"] == n and eng.last_stats["inner_iters_total"] == int(it0[..., 0].sum())
+        assert np.array_equal(it0, it1) and np.array_equal(f0, f1)
+        spread = it0[..., 0].sum(axis=(1, 2))
+        assert spread.max() > 1.5 * spread.min(), "the batch should mix fast and slow pairs"
+        for b in (0, 3, 5, cap - 1, cap, n - 1):                          # first / last of a unit, a zero-flow pair, an unrelated pair
+            ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], return_iters=True)
+            assert np.array_equal(it1[b], ref_it[:nl]) and np.array_equal(f1[b], ref), f"pair {b}"
+        for lanes in (1, 2, 5):                                           # any lane count, same bits
+            eng.set_tuning("queue_lanes", lanes)
+            f2 = np.array(eng.calc_pairs(I0s, I1s))
+            assert eng.counter("queue_lanes") == lanes
+            assert np.array_equal(f2, f0) and np.array_equal(eng.last_iters(), it0)
+    finally:
+        eng.close()
+
+
+def test_queue_sequence_mode_units_share_their_boundary_frame(oracle):
+    from tee_optical_flow_amd.synth import speckle_sequence
+    frames = speckle_sequence(9, 50, 80, 112)
+    eng = _engine(16)
+    try:
+        eng.set_tuning("queue_lanes", 0)
+        f0 = np.array(eng.calc_batch(frames, scale=1.5)); it0 = eng.last_iters().copy()
+        eng.set_tuning("queue_lanes", -1)
+        f1 = np.array(eng.calc_batch(frames, scale=1.5))
+        assert eng.counter("queue_units_done") == 4                        # 49 pairs: 16 + 16 + 16 + 1
+        assert np.array_equal(f0, f1) and np.array_equal(it0, eng.last_iters())
+        for i in (0, 15, 16, 47, 48):
+            assert np.array_equal(f1[i], oracle.tvl1_calc(frames[i], frames[i + 1]) * np.float32(1.5))
+    finally:
+        eng.close()
+
+
+def test_a_failing_sub_batch_drains_every_lane_before_the_call_returns(oracle):
+    import tee_optical_flow_amd as T
+    I0s, I1s = _mixed(64, 72, 96, seed0=40)
+    eng = _engine(16)
+    try:
+        good = np.array(eng.calc_pairs(I0s, I1s)); it = eng.last_iters().copy()
+        done0 = eng.counter("queue_units_done")
+        eng.set_tuning("queue_test_fail_unit", 1)                          # the lane that takes unit 1 reports a failure instead of solving it
+        with pytest.raises(T.OpticalFlowCalculationError, match=r"sub-batch 1 \(pairs 16\.\.31\).*injected"):
+            eng.calc_pairs(I0s, I1s)
+        # units 0 and 2 were running on the other lanes and finished; unit 3 was never started; nothing is queued or in flight
+        assert eng.counter("queue_outstanding") == 0
+        assert eng.counter("queue_units_done") - done0 + eng.counter("queue_units_skipped") == 3
+        assert eng.counter("queue_units_skipped") >= 1
+        again = np.array(eng.calc_pairs(I0s, I1s))                         # the handle is whole: same bits as before
+        assert np.array_equal(again, good) and np.array_equal(eng.last_iters(), it)
+        eng.set_tuning("queue_test_fail_unit", 3)                          # the last unit fails: everything else has been solved
+        with pytest.raises(T.OpticalFlowCalculationError, match="sub-batch 3"):
+            eng.calc_pairs(I0s, I1s)
+        assert eng.counter("queue_outstanding") == 0
+        assert np.array_equal(np.array(eng.calc_pairs(I0s, I1s)), good)
+    finally:
+        eng.close()
+
+
+def test_jobs_in_flight_are_collected_in_any_order(oracle):
+    """tf_submit_pairs / tf_submit_seq: three jobs queued before the first wait; each wait hands back that job's flows, statistics
+    and iteration counts; a synchronous call made meanwhile queues behind them."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_sequence
+    sets = [_mixed(n, 64, 88, seed0=s) for n, s in ((20, 10), (9, 200), (33, 400))]
+    frames = speckle_sequence(4, 12, 64, 88)
+    eng = _engine(8)
+    try:
+        want = []
+        for I0s, I1s in sets:
+            f = np.array(eng.calc_pairs(I0s, I1s))
+            want.append((f, eng.last_iters().copy()))
+        want_seq = np.array(eng.calc_batch(frames, scale=3.0))
+        t0 = eng.submit_pairs(*sets[0])
+        t1 = eng.submit_pairs(*sets[1])
+        ts = eng.submit_batch(frames, scale=3.0)
+        t2 = eng.submit_pairs(*sets[2])
+        sync = np.array(eng.calc_pairs(*sets[1]))                          # queues behind the four jobs
+        assert np.array_equal(sync, want[1][0])
+        for t, k in ((t2, 2), (t0, 0), (t1, 1)):
+            got = eng.wait(t)
+            assert eng.last_stats["n_pairs"] == len(sets[k][0])
+            assert np.array_equal(got, want[k][0]) and np.array_equal(eng.last_iters(), want[k][1]), f"job {k}"
+        assert np.array_equal(eng.wait(ts), want_seq)
+        with pytest.raises(T.OpticalFlowCalculationError, match="unknown ticket"):
+            eng.wait(t0)
+        assert eng.counter("queue_outstanding") == 0
+        ref, ref_it, nl = oracle.tvl1_calc(sets[2][0][32], sets[2][1][32], return_iters=True)
+        assert np.array_equal(want[2][0][32], ref) and np.array_equal(want[2][1][32], ref_it[:nl])
+    finally:
+        eng.close()
+
+
+def test_device_jobs_in_flight_and_close_with_jobs_queued():
+    import torch
+    I0s, I1s = _mixed(24, 64, 88, seed0=70)
+    dev = torch.device("cuda", 0)
+    fr = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)
+    p0, p1 = fr.data_ptr(), fr.data_ptr() + 24 * 64 * 88
+    out = [torch.zeros((24, 64, 88, 2), dtype=torch.float32, device=dev) for _ in range(4)]
+    eng = _engine(8)
+    try:
+        eng.calc_pairs_device(p0, p1, 24, 64, 88, out[0].data_ptr())
+        ref = out[0].cpu().numpy()
+        tk = [eng.submit_pairs_device(p0, p1, 24, 64, 88, out[k].data_ptr(), scale=float(k)) for k in (1, 2, 3)]
+        for k, t in zip((1, 2, 3), tk):
+            st = eng.wait(t)
+            assert st["n_pairs"] == 24
+            assert np.array_equal(out[k].cpu().numpy(), ref * np.float32(k))
+        for k in (1, 2, 3):                                                # closing with jobs queued: the lanes finish them first
+            eng.submit_pairs_device(p0, p1, 24, 64, 88, out[k].data_ptr())
+    finally:
+        eng.close()
+    torch.cuda.synchronize()
+    for k in (1, 2, 3):
+        assert np.array_equal(out[k].cpu().numpy(), ref)
+
+
+def test_deepflow_through_the_queue(oracle):
+    import tee_optical_flow_amd as T
+    I0s, I1s = _mixed(20, 96, 160, seed0=500)
+    eng = T.DenseFlow(device_id=0, max_batch=8, algo="deepflow")
+    try:
+        eng.set_tuning("queue_lanes", 0)
+        f0 = np.array(eng.calc_pairs(I0s, I1s))
+        eng.set_tuning("queue_lanes", -1)
+        f1 = np.array(eng.calc_pairs(I0s, I1s))
+        assert eng.counter("queue_lanes") == 1 and eng.counter("queue_units_done") == 3
+        assert np.array_equal(f0, f1)
+        eng.set_tuning("queue_lanes", 2)
+        t = eng.submit_pairs(I0s, I1s)
+        assert np.array_equal(eng.wait(t), f0)
+        for b in (0, 8, 19):
+            assert np.array_equal(f1[b], oracle.deepflow_calc(I0s[b], I1s[b]))
+    finally:
+        eng.close()
