@@ -1,22 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pairs/s of the MI355X DualTVL1 path (BASELINE.json metric), plus a DeepFlow leg (BASELINE configs[3]).
 
-One "step" = one pass of the hot path over one batch: every rank solves `--batch` (default 128) independent
-512x512 uint8 frame pairs (synthetic "speckle-warp v1"; pair shape of BASELINE configs[1],
-per-GPU shard size of configs[2]) with all-default DualTVL1 (lambda 0.15), inputs already resident in HBM, and --
-for N > 1 -- the (u,v) fields are all-gathered over RCCL (the one exchange step north_star names), overlapped
+One "step" = one pass of the hot path over one batch = ONE synchronous call of the C-ABI boundary (tf_calc_pairs_device): every rank
+solves `--batch` (default 384) independent 512x512 uint8 frame pairs (synthetic "speckle-warp v1"; pair shape of
+BASELINE configs[1]; three sub-batches of configs[2]'s per-GPU shard size, 128) with all-default DualTVL1 (lambda 0.15), inputs already
+resident in HBM, and -- for N > 1 -- the (u,v) fields are all-gathered over RCCL (the one exchange step north_star names), overlapped
 with the next step's compute.  value = pairs all ranks solved / max-over-ranks wall time.
 
-Steps are independent batches, and the K timed steps are bracketed by a barrier + synchronize on both sides, not separated by
-one: by default three engines (handle + stream + host thread each) take whole steps in turn (`--in-flight 3`), so that one
-step's tail overlaps the next step's start -- what a folder of studies or a stream of batches gives a deployment for free.
-`--in-flight 1` is the form rounds 1-3 measured (one engine, each step split over two lanes and joined at its end); the
-default N=1 run times it too, right after, and reports it under "steps_joined".  Every step does the same work in both forms
-(bit-identical flows: tools/pipelined_steps.py, tests/test_gpu_batches.py::test_engine_pool_gives_the_single_engines_flows).
+Inside the call the LIBRARY cuts the batch into 128-pair sub-batches that its three lanes (engines of their own: stream, buffers, host
+thread) take from a queue, so one sub-batch's tail runs under the others' full launches (include/teeflow.h "Sub-batches and lanes").
+Round 4 reached that overlap with three engines driven by Python threads in this file; rounds 1-3 timed 128-pair calls that were split
+in two contiguous halves and joined -- the default N=1 run still times that form right after and reports it as "steps_joined", and
+the same 128-pair batches submitted without waiting (tf_submit_pairs_device, three in flight) as "jobs_in_flight".  `--in-flight E`
+(E > 1) makes the timed region itself use tf_submit_* with E steps in flight.  Every pair's flow is bit-identical in all forms
+(tests/test_gpu_queue.py, tools/queue_forms.py).
 
 The default N=1 run then measures BASELINE configs[3] (OF_algo='deepflow', the algorithm the reference's own CLI
-hard-codes, calculate_optical_flow.py:735-739) the same way on 128 pairs and reports it under "deepflow" in the
-same JSON line.
+hard-codes, calculate_optical_flow.py:735-739) on 128 pairs per call and reports it under "deepflow" in the same JSON line.
 
 Everything that is not GPU work (synthetic inputs, the optional `--pmc` counter passes, which run this script as a
 child under rocprofv3) happens BEFORE the first GPU call, so no process is ever started from a GPU-initialised one.
@@ -225,7 +225,7 @@ def pmc_child_passes(algo, out_dir, tag="live"):
         d = os.path.join(out_dir, f"pmc_{tag}_{algo}_{ctr}")
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-include-regex", kern, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile",
-               "--in-flight", "1", "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo] + (["--batch", "128"] if algo != "TVL1" else [])
+               "--in-flight", "1", "--lanes", "1", "--no-deepflow", "--steps-only", "--algo", algo, "--batch", "128"]     # one sub-batch, one lane: the launches the event pairs time
         env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
         r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         if r.returncode != 0:
@@ -326,68 +326,39 @@ def launch_profile(eng):
     return lv[:n], wp[:n], it[:n], ms[:n]
 
 
-def run_steps_in_flight(first, n, E, solve, issue=None, retire=None):
-    """Steps first .. first+n-1 with E of them in flight: step k is solved by engine k % E into that engine's flow buffer (k // E) & 1
-    (`solve(k)` -> its statistics; host-synchronous, so a step's flows are complete when it returns).  Every engine has its own host
-    thread; the collectives (`issue((engine, buffer))` / `retire((engine, buffer))`, None on a single rank) are called by THIS thread
-    only, `issue` in step order -- RCCL needs the same order on every rank -- and `retire` one step of the same engine later; a worker
-    does not solve into a buffer again before the all-gather that read it has been retired.  E = 1 is the plain loop.  An exception in
-    any solve is re-raised here after every thread has come home.  Returns the n statistics in step order."""
-    key = lambda k: (k % E, (k // E) & 1)
-    stats = [None] * n
-    if E == 1:
-        for i in range(n):
-            if retire:
-                retire(key(first + i))
-            stats[i] = solve(first + i)
-            if issue:
-                issue(key(first + i))
-        return stats
-    import threading
-    done = [threading.Event() for _ in range(n)]
-    free = [threading.Event() for _ in range(n)] if issue else []     # step i's buffer: the all-gather that read it has finished
-    failed = []
+def run_steps_pipelined(first, n, E, nbuf, submit, collect, issue=None, retire=None):
+    """Steps first .. first+n-1 on ONE host thread with at most E of them submitted and not yet collected.  Step k's flows go to
+    buffer k % nbuf.  `submit(k, buf)` starts the step and returns what `collect(...)` turns into its statistics (E = 1: submit IS
+    the synchronous solve and collect is the identity; E > 1: tf_submit_* / tf_wait -- the overlap happens on the library's lanes,
+    not here).  Collectives (None on a single rank): `issue(buf)` right after the step that filled the buffer has been collected --
+    so in step order, as RCCL needs on every rank -- and `retire(buf)` (host-blocking) before a buffer is solved into again; with
+    nbuf > E the all-gather of a step has the whole next step to finish.  An exception leaves nothing submitted and uncollected.
+    Returns the n statistics in step order; the last min(n, nbuf) all-gathers are left for the caller's drain."""
+    from collections import deque
+    assert E >= 1 and nbuf >= E
+    stats, inflight = [], deque()
 
-    def worker(e_):
-        try:
-            for i in range(n):
-                if (first + i) % E != e_:
-                    continue
-                if issue and i - 2 * E >= 0:
-                    free[i - 2 * E].wait()                # this buffer's previous flows have left
-                if failed:
-                    return
-                stats[i] = solve(first + i)
-                done[i].set()
-        except BaseException as ex:                       # never leave the main thread or another worker waiting
-            failed.append(ex)
-            for d_ in done + free:
-                d_.set()
-    th = [threading.Thread(target=worker, args=(e_,)) for e_ in range(E)]
-    for t in th:
-        t.start()
+    def collect_oldest():
+        k0, h0 = inflight.popleft()
+        stats.append(collect(h0))
+        if issue:
+            issue(k0 % nbuf)
     try:
-        for i in range(n):
-            done[i].wait()
-            if failed:
-                break
-            if issue:
-                issue(key(first + i))
-                if i - E >= 0:                            # the step before it on the same engine: its all-gather has had a whole step to finish
-                    retire(key(first + i - E))
-                    free[i - E].set()
-    except BaseException as ex:
-        failed.append(ex)
-    finally:
-        for f_ in free:                                   # nobody in this call waits for the last E; the caller's drain retires them
-            f_.set()
-        if failed:
-            for d_ in done:
-                d_.set()
-        for t in th:
-            t.join()
-    if failed:
-        raise failed[0]
+        for k in range(first, first + n):
+            if len(inflight) == E:
+                collect_oldest()
+            if retire:
+                retire(k % nbuf)
+            inflight.append((k, submit(k, k % nbuf)))
+        while inflight:
+            collect_oldest()
+    except BaseException:
+        while inflight:                                   # whatever failed, nothing of this loop stays in flight
+            try:
+                collect(inflight.popleft()[1])
+            except Exception:
+                pass
+        raise
     return stats
 
 
@@ -395,35 +366,26 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     import tee_optical_flow_amd as T
     H = W = a.size
     frames = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)       # [2B,H,W] u8, resident in HBM
-    # Steps in flight.  A step is one batch of B pairs through one engine (handle + stream).  Consecutive steps are independent, so E
-    # engines take whole steps in turn (step k on engine k % E, each driven by its own host thread) and the tail of one step -- few
-    # pairs still iterating, the fine levels done -- overlaps the start of the next, as consecutive studies of a folder would.  E = 1
-    # is the older form: one engine, the step split over `--lanes` lanes that are joined at the step's end.  DeepFlow stays at E = 1:
-    # its co-resident SOR launches take every CU.  Every step's work is the same in both forms (flows bit-identical, tools/pipelined_steps.py).
-    E = max(1, a.in_flight) if algo == "TVL1" else 1
-    lanes_each = a.lanes if E == 1 else 1
-    flows = [[torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(2)] for _ in range(E)]
+    SUB = min(a.sub_batch, B)                             # pairs per sub-batch (the engine's max_batch): what one lane solves at a time
+    # ONE engine.  A step is one synchronous tf_calc_pairs_device call of B pairs; when B > SUB the library cuts it into sub-batches that
+    # its lanes take from a queue (three lanes for DualTVL1, one for DeepFlow, whose co-resident SOR launches take every CU; a call of at
+    # most SUB pairs is split in `--lanes` contiguous parts and joined).  `--in-flight E` > 1: steps are submitted without waiting
+    # (tf_submit_pairs_device), E in flight -- the same lanes, the overlap reaching across steps.
+    E = max(1, a.in_flight)
+    NBUF = E + 1
+    flows = [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(NBUF)]
     gdev = dev if a.backend == "nccl" else torch.device("cpu")
-    gathered = [[torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(2)] for _ in range(E)] if world > 1 else None
+    gathered = [torch.empty((world * B, H, W, 2), dtype=torch.float32, device=gdev) for _ in range(NBUF)] if world > 1 else None
     tuning = [kv.split("=") for kv in a.tuning.split(",") if kv]
-    engines = []
-    for _ in range(E):
-        e_ = T.DenseFlow(device_id=local_rank, max_batch=B, algo=algo)
-        e_.set_tuning("lanes", lanes_each)
-        for k, v in tuning:
-            e_.set_tuning(k, int(v))
-        engines.append(e_)
-    eng = engines[0]                                  # the instrumented repeats and the latency extras use this one
-    # N > 1 with steps in flight: the communicator lives on a handle of its own that never solves, so that an all-gather is ordered
-    # behind nothing but the step whose flows it carries (tf_allgather_flows waits for its handle's solve stream)
-    comm_eng = eng if (E == 1 or world == 1) else T.DenseFlow(device_id=local_rank, max_batch=1, algo=algo)
-    # The engine runs on its own non-blocking HIP stream and every call is host-synchronous: when it returns the flows are
-    # complete, so the RCCL all-gather (torch's stream) may start at once.  The opposite direction needs an explicit host
-    # wait: Work.wait() only orders torch's CURRENT STREAM behind the collective, it does not block the host, and the
-    # engine's stream is not ordered against either -- so before a buffer is solved into again the host waits until the
-    # all-gather that read it has really finished.
+    eng = T.DenseFlow(device_id=local_rank, max_batch=SUB, algo=algo)
+    eng.set_tuning("lanes", a.lanes)
+    for k, v in tuning:
+        eng.set_tuning(k, int(v))
+    # Every tf_calc_* is host-synchronous (its lanes have drained when it returns) and tf_wait likewise: a step's flows are complete
+    # when its all-gather is issued, on whatever stream they were produced.  The opposite direction needs an explicit host wait: before
+    # a buffer is solved into again the host waits (tf_comm_wait) until the all-gather that read it has really finished.
     p0, p1 = frames.data_ptr(), frames.data_ptr() + B * H * W
-    pending = {}                                      # (engine, buffer) -> the all-gather that is reading that flow buffer
+    pending = {}                                      # flow buffer -> the all-gather that is reading it
     # The exchange is the library's own: tf_allgather_flows = ncclAllGather on librccl, issued on the engine's communication
     # stream (include/teeflow.h); torch.distributed only carries the 128-byte communicator id.  If RCCL cannot be set up
     # that way (or on the gloo rehearsal backend) the step falls back to torch's all_gather_into_tensor and says so.
@@ -434,7 +396,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         if a.backend == "nccl" and not a.torch_collective:
             try:
                 from tee_optical_flow_amd.distributed import init_engine_comm, torch_id_exchange
-                init_engine_comm(comm_eng, rank, world, torch_id_exchange())
+                init_engine_comm(eng, rank, world, torch_id_exchange())
                 lib_comm = True
                 collective = "tf_allgather_flows: ncclAllGather issued by the library on its own stream (librccl over xGMI)"
             except Exception as e:                       # keep the N>1 run alive; the line records which path ran
@@ -445,37 +407,37 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             lib_comm = False
             collective = "torch.distributed.all_gather_into_tensor (another rank could not join the library communicator)"
 
-    def retire(key):
-        tk = pending.pop(key, None)
+    def retire(buf):
+        tk = pending.pop(buf, None)
         if tk is not None:
             if lib_comm:
-                comm_eng.comm_wait(tk)                   # host-blocking: the buffer is free for the next solve
+                eng.comm_wait(tk)                        # host-blocking: the buffer is free for the next solve
             else:
                 tk.wait()
                 if dev.type == "cuda":
                     torch.cuda.current_stream(dev).synchronize()
 
-    def issue_gather(key):
-        e_, buf = key
+    def issue_gather(buf):
         if lib_comm:
-            pending[key] = comm_eng.allgather(flows[e_][buf].data_ptr(), flows[e_][buf].numel(), gathered[e_][buf].data_ptr())
+            pending[buf] = eng.allgather(flows[buf].data_ptr(), flows[buf].numel(), gathered[buf].data_ptr())
         else:
-            src = flows[e_][buf] if a.backend == "nccl" else flows[e_][buf].cpu()
-            pending[key] = dist.all_gather_into_tensor(gathered[e_][buf], src, async_op=True)
+            src = flows[buf] if a.backend == "nccl" else flows[buf].cpu()
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf], src, async_op=True)
 
-    def slot(k):
-        return k % E, (k // E) & 1                        # step k: engine, flow buffer
+    def submit(k, buf):
+        if E == 1:
+            return eng.calc_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())      # one call of the boundary = one step
+        return eng.submit_pairs_device(p0, p1, B, H, W, flows[buf].data_ptr())
 
-    def solve(k):
-        e_, buf = slot(k)
-        return engines[e_].calc_pairs_device(p0, p1, B, H, W, flows[e_][buf].data_ptr())
+    def collect(hd):
+        return hd if E == 1 else eng.wait(hd)
 
     def run_steps(first, n):
-        return run_steps_in_flight(first, n, E, solve, issue_gather if world > 1 else None, retire if world > 1 else None)
+        return run_steps_pipelined(first, n, E, NBUF, submit, collect, issue_gather if world > 1 else None, retire if world > 1 else None)
 
     def drain():
-        for key in list(pending):
-            retire(key)
+        for buf in list(pending):
+            retire(buf)
 
     def fence():
         drain()
@@ -484,8 +446,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for e_ in engines:                                    # set-up, not a step: every engine allocates its buffers
-        e_.calc_pairs_device(p0, p1, B, H, W, flows[0][0].data_ptr())
+    eng.calc_pairs_device(p0, p1, B, H, W, flows[0].data_ptr())          # set-up, not a step: every lane allocates its buffers
     run_steps(0, warmup)
     fence()
     t0 = time.perf_counter()
@@ -500,8 +461,9 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    last_e, last_buf = slot(warmup + steps - 1)
-    last_flow = flows[last_e][last_buf]
+    last_buf = (warmup + steps - 1) % NBUF
+    last_flow = flows[last_buf]
+    queue_lanes = eng.counter("queue_lanes")
     gather_ok = None
     if world > 1:
         # every rank's shard must have arrived intact everywhere: compare checksums of the gathered segments with the
@@ -510,41 +472,61 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         mine = bits(last_flow).sum().reshape(1).to(gdev)
         sums = torch.empty(world, dtype=torch.int64, device=gdev)
         dist.all_gather_into_tensor(sums, mine)
-        seg = bits(gathered[last_e][last_buf]).view(world, -1).sum(1)
+        seg = bits(gathered[last_buf]).view(world, -1).sum(1)
         gather_ok = bool(torch.equal(seg.cpu(), sums.cpu()))
-    # The same K steps in the older form (one engine, the step split over two lanes joined at its end), for the record beside `value`
-    joined = None
-    if E > 1 and world == 1:
-        eng.set_tuning("lanes", a.lanes)
-        eng.calc_pairs_device(p0, p1, B, H, W, flows[0][0].data_ptr())
+    # The same pairs in the two other forms, for the record beside `value` (N = 1): (i) SUB-pair calls, each split over `--lanes`
+    # contiguous parts and joined at its end -- what rounds 1-3 timed; (ii) SUB-pair jobs submitted without waiting, three in flight.
+    npx = H * W
+    subs = [(c, min(SUB, B - c)) for c in range(0, B, SUB)]
+    joined = inflight = None
+    if world == 1 and B > SUB and not a.steps_only:
+        def sub_call(c, nb, buf, fn):
+            return fn(p0 + c * npx, p1 + c * npx, nb, H, W, flows[buf].data_ptr() + c * npx * 8)
+        for c, nb in subs:
+            sub_call(c, nb, 0, eng.calc_pairs_device)
         torch.cuda.synchronize(dev)
         tj = time.perf_counter()
         for k in range(steps):
-            eng.calc_pairs_device(p0, p1, B, H, W, flows[0][k & 1].data_ptr())
+            for c, nb in subs:
+                sub_call(c, nb, k & 1, eng.calc_pairs_device)
         torch.cuda.synchronize(dev)
         dj = time.perf_counter() - tj
-        joined = {"value": B * steps / dj, "unit": "frame-pairs/s", "ms_per_step": dj / steps * 1e3, "engines": 1, "lanes": a.lanes,
-                  "note": "one engine, every step split over its lanes and joined at its end (rounds 1-3 measured this form)"}
-        eng.set_tuning("lanes", lanes_each)
-    # Roofline leg: the SAME K steps again, one lane, with every launch of the dominant kernel bracketed by a HIP event
-    # pair on the engine's stream.  Kept out of the timed region above (the event records cost a few % of a step).
+        joined = {"value": B * steps / dj, "unit": "frame-pairs/s", "ms_per_call": dj / (steps * len(subs)) * 1e3, "pairs_per_call": SUB, "lanes": a.lanes,
+                  "note": f"one synchronous call per {SUB} pairs, each split over {a.lanes} contiguous parts and joined at its end (the form rounds 1-3 timed as a step)"}
+        tk = []
+        tj = time.perf_counter()
+        for k in range(steps):
+            for c, nb in subs:
+                if len(tk) == 3:
+                    eng.wait(tk.pop(0))
+                tk.append(sub_call(c, nb, k & 1, eng.submit_pairs_device))
+        while tk:
+            eng.wait(tk.pop(0))
+        torch.cuda.synchronize(dev)
+        dj = time.perf_counter() - tj
+        inflight = {"value": B * steps / dj, "unit": "frame-pairs/s", "pairs_per_job": SUB, "jobs_in_flight": 3,
+                    "note": f"tf_submit_pairs_device of {SUB}-pair jobs, three in flight, one host thread (the library's lanes take whole jobs)"}
+    # Roofline leg: the SAME pairs again as SUB-pair calls on ONE lane (no queue, no split), with every launch of the dominant kernel
+    # bracketed by a HIP event pair on the engine's stream.  Kept out of the timed region above (the event records cost a few % of a
+    # step); roofline.timed_regime describes the kernel in the regime the timed region runs in.
     prof = None
     if not a.no_profile:
-        eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include the other lane's kernels
+        eng.set_tuning("lanes", 1)      # one lane: a launch's event-pair time must not include another lane's kernels
         eng.set_profile(1)
         for k in range(steps):
-            last_flow = flows[0][k & 1]
-            st = eng.calc_pairs_device(p0, p1, B, H, W, last_flow.data_ptr())
-            acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
-            acc["sor_px"] += st["iter_pair_steps"]
-            for kk in ("ms_warp", "ms_median", "ms_misc", "ms_sched", "ms_device"):
-                acc["p_" + kk] = acc.get("p_" + kk, 0.0) + st[kk]
+            last_flow = flows[k & 1]
+            for c, nb in subs:
+                st = eng.calc_pairs_device(p0 + c * npx, p1 + c * npx, nb, H, W, last_flow.data_ptr() + c * npx * 8)
+                acc["iter_ms"] += st["iter_ms"]; acc["iter_bytes"] += st["iter_bytes"]; acc["iter_launches"] += st["iter_launches"]
+                acc["sor_px"] += st["iter_pair_steps"]
+                for kk in ("ms_warp", "ms_median", "ms_misc", "ms_sched", "ms_device"):
+                    acc["p_" + kk] = acc.get("p_" + kk, 0.0) + st[kk]
         drain()
         torch.cuda.synchronize(dev)
         if algo == "TVL1":
             prof = launch_profile(eng)
         eng.set_profile(0)
-        eng.set_tuning("lanes", lanes_each)
+        eng.set_tuning("lanes", a.lanes)
 
     out = None
     if rank == 0:
@@ -594,7 +576,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                 "traffic": traffic, "traffic_source": traffic_source, "achieved_basis": basis,
                 "avg_launch_ms": avg_launch_ms, "launches": acc["iter_launches"], "launches_per_step": acc["iter_launches"] / max(steps, 1),
                 ("px_iterations_per_launch" if algo == "TVL1" else "px_sweeps_per_launch"): units_per_launch,
-                "measured_on": f"{steps} instrumented repeats of the timed steps, single lane (one HIP event pair per launch, engine stream)"}
+                "measured_on": f"{steps} instrumented repeats of the timed steps' pairs as single-lane {SUB}-pair calls (one HIP event pair per launch, engine stream; the GPU to itself)"}
         rate = units_per_launch / secs if secs else None
         roof["algorithmic_bytes_per_launch"] = comp_per_launch
         roof["algorithmic_GBps"] = comp_per_launch / 1e9 / secs if secs else None
@@ -652,7 +634,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                 lv, wp, it, ms = prof
                 m = (lv == 0) & (it == 0) & (ms > 0)             # first launch of a level-0 stage: all B pairs iterate, 2 iterations
                 if m.any():
-                    full = float(np.median(B * H * W * 2.0 / (ms[m] * 1e-3)))
+                    full = float(np.median(SUB * H * W * 2.0 / (ms[m] * 1e-3)))      # (the instrumented calls hold SUB pairs each)
             isa, why = stored_record("isa_stats.json", kern)
             valu = {"px_iterations_per_s_all_launches": rate, "px_iterations_per_s_full_launches": full}
             if isa:
@@ -669,14 +651,18 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
-                                   "configs[2] per-GPU shard), speckle-warp v1 seeds rank*B..; "
+                                   f"{len(subs)} sub-batch(es) of configs[2]'s per-GPU shard size {SUB}) in ONE call of the boundary, speckle-warp v1 seeds rank*B..; "
                                    + ("DualTVL1 all defaults, lambda 0.15, 5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; "
                                       if algo == "TVL1" else
                                       "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
                                    + "inputs resident in HBM; "
                                    + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
-                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}", "steps_in_flight": E, "lanes_per_engine": lanes_each,
-                       "lanes_per_gpu": E * lanes_each},
+                       "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}",
+                       "calls_per_step": 1, "boundary_call": ("tf_calc_pairs_device (synchronous)" if E == 1 else f"tf_submit_pairs_device / tf_wait, {E} steps in flight"),
+                       "sub_batch_pairs": SUB, "sub_batches_per_step": len(subs),
+                       # what overlaps inside the library (include/teeflow.h "Sub-batches and lanes"): lanes that take whole sub-batches from a queue
+                       "steps_in_flight": E, "library_queue_lanes": queue_lanes if B > SUB or E > 1 else 0,
+                       "lanes_per_sub_batch_call": a.lanes if B <= SUB and E == 1 else (a.lanes if algo != "TVL1" else 1)},
             # data-independent rate of the whole job: executed pixel-iterations (pixel-sweeps) per second of the timed region
             ("px_iterations_per_s" if algo == "TVL1" else "px_sweeps_per_s"): world * acc["timed_iter_bytes"] / unit_bytes / dt,
             "roofline": roof,
@@ -687,7 +673,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         if not a.no_profile and algo == "TVL1":
             # where a step's device time goes, from the library's own event pairs (instrumented single-lane repeats)
             out["stage_ms_per_step"] = {"tvl1_iter": acc["iter_ms"] / steps, "warp": acc.get("p_ms_warp", 0.0) / steps,
-                                        "median": acc.get("p_ms_median", 0.0) / steps, "device_total": acc.get("p_ms_device", 0.0) / steps}
+                                        "median": acc.get("p_ms_median", 0.0) / steps, "device_total": acc.get("p_ms_device", 0.0) / steps,
+                                        "note": f"summed over the {len(subs)} single-lane {SUB}-pair calls that make up a step's {B} pairs (exclusive use of the GPU, not the timed regime)"}
         if algo == "TVL1":
             out["executed_inner_iterations_per_pair"] = acc["inner"] / (B * steps)
             out["executed_outer_iterations_per_pair"] = acc["outer"] / (B * steps)
@@ -698,6 +685,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             out["sor_coresident"] = {"launches": eng.counter("coop_launches"), "calls_repeated_tiled": eng.counter("coop_aborts")}
         if joined is not None:
             out["steps_joined"] = joined
+            out["jobs_in_flight"] = inflight
         out["collective"] = collective
         if gather_ok is not None:
             out["allgather_checksums_match"] = gather_ok
@@ -722,18 +710,6 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         tp = time.perf_counter()
         eng.calc_pairs(I0s, I1s)
         out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
-        if E > 1:
-            # the same through every engine at once (one host thread each, two calls per engine): one batch's copies run under another's solve
-            from concurrent.futures import ThreadPoolExecutor
-
-            def twice(e_):
-                e_.calc_pairs(I0s, I1s)
-                e_.calc_pairs(I0s, I1s)
-            with ThreadPoolExecutor(E) as tpool:
-                list(tpool.map(lambda e_: e_.calc_pairs(I0s, I1s), engines))      # fills each engine's pinned pool
-                tp = time.perf_counter()
-                list(tpool.map(twice, engines))
-                out["pcie_inclusive_pairs_per_s_steps_in_flight"] = 2 * E * B / (time.perf_counter() - tp)
         if world == 1 and not a.no_cpu_baseline:
             n = min(cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n, algo)
@@ -750,10 +726,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                     out["mean_epe_vs_opencv"] = float(np.mean(epe))
                     out["cpu_baseline"] = cvb       # the real thing replaces the restatement as THE baseline
                     out["cpu_baseline_port"] = cb
-    if comm_eng is not eng:
-        comm_eng.close()
-    for e_ in engines:
-        e_.close()
+    eng.close()
     del frames, flows, gathered
     return out
 
@@ -763,7 +736,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per GPU per step = per call of the boundary (default 384 DualTVL1, 128 DeepFlow)")
+    ap.add_argument("--sub-batch", type=int, default=128, help="pairs per sub-batch = the engine's max_batch (BASELINE configs[2]'s per-GPU shard size)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
@@ -775,11 +749,11 @@ def main():
     ap.add_argument("--pmc", action="store_true", help="N=1 only: first run the FETCH_SIZE / WRITE_SIZE counter passes of this command as child "
                                                        "processes under rocprofv3 (adds ~1-2 min), so roofline.traffic is measured in this run")
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_live"))
-    ap.add_argument("--round-tag", default="r03")
+    ap.add_argument("--round-tag", default="r05")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps: no single-pair latency, no PCIe step (what the counter passes profile)")
-    ap.add_argument("--in-flight", type=int, default=3, help="DualTVL1: engines that take whole steps in turn, i.e. steps in flight per GPU (each engine one lane); "
-                                                             "1 = one engine, each step split over --lanes lanes and joined at its end")
-    ap.add_argument("--lanes", type=int, default=2, help="engine lanes (handle+stream+host thread) a step is split over; 1 for clean per-kernel profiles")
+    ap.add_argument("--in-flight", type=int, default=1, help="1 = every step is one synchronous call (default); E > 1 = steps are submitted with tf_submit_pairs_device, "
+                                                             "E in flight (the library's lanes overlap them; one host thread)")
+    ap.add_argument("--lanes", type=int, default=2, help="contiguous parts a call of at most one sub-batch is split over (joined at its end); 1 for clean per-kernel profiles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--torch-collective", action="store_true", help="N>1: all-gather through torch.distributed instead of the library's tf_allgather_flows")
@@ -801,6 +775,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     # ---- CPU-only preparation: nothing below this block may start a process ------------------------------------
+    if a.batch is None:
+        a.batch = 384 if a.algo == "TVL1" else 128
     B, H, W = a.batch, a.size, a.size
     I0s, I1s = make_inputs(range(rank * B, (rank + 1) * B), H, W)          # rank r owns pairs [rB, (r+1)B): no data-path exchange
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not under_profiler():

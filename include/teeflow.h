@@ -221,7 +221,15 @@ int tf_radlong_select(tf_handle* h, int which, const long long* ranks, double* v
  *      on the handle's communication stream behind the work already queued on its solve stream and returns at once with
  *      a ticket; tf_comm_wait(h, ticket) blocks the host until that all-gather is done (ticket < 0: all of them), which
  *      is what must happen before d_send / d_recv are reused -- so the exchange of step k overlaps the solve of step k+1.
- *      tf_allgather_flows_all is the single-process form: grouped calls for all n ranks, returns when all are done. */
+ *      tf_allgather_flows_all is the single-process form: grouped calls for all n ranks, returns when all are done.
+ *      ORDER against the solve that produced d_send, stated: tf_allgather_flows orders the collective behind the work queued on
+ *      THIS handle's solve stream and nothing else.  Flows written by the handle's lanes (a call larger than one sub-batch, a
+ *      tf_submit_* job) or by ANOTHER handle (a communicator handle that never solves, as round 4's bench.py used) are ordered
+ *      by the HOST, by design: every tf_calc_* is host-synchronous and so is tf_wait -- when they have returned, every stream
+ *      that worked for them has drained, and the all-gather may be issued at once.  There is no earlier point to hook a stream
+ *      dependency on: a solve's launches are issued as its stop reports come back (the iteration count is data-dependent), so
+ *      until the call returns the producing streams do not yet hold all of its work, and an event recorded on them would order
+ *      the collective behind a prefix of the solve only.  Issue the all-gather after the producing call / tf_wait has returned. */
 #define TF_COMM_ID_BYTES 128
 int tf_comm_unique_id(unsigned char* id /* [TF_COMM_ID_BYTES] */);
 int tf_comm_init_rank(tf_handle* h, int nranks, int rank, const unsigned char* id);
@@ -255,7 +263,7 @@ int tf_device_count(void);
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* counters of the handle for tests and tools: "coop_launches" (launches of the co-resident SOR form since the handle was made),
  * "coop_aborts" (calls repeated with the tiled form because such a launch gave up waiting), "coop_disabled"; "queue_jobs", "queue_units_done",
- * "queue_units_skipped" (sub-batches dropped because an earlier one of their call had failed), "queue_outstanding", "queue_lanes";
+ * "queue_units_failed", "queue_units_skipped" (sub-batches dropped because an earlier one of their call had failed), "queue_outstanding", "queue_lanes";
  * "experimental" (1: built with the experimental tvl1_iter forms); -1 for an unknown name */
 long long tf_dbg_counter(tf_handle* h, const char* name);
 /* DeepFlow hooks: one cv::VariationalRefinement::calcUV on dense float images (u, v updated in place); 3x3 Gaussian blur */

@@ -191,7 +191,7 @@ struct tf_handle : TfKnobs {
     int queue_test_fail_unit = -1;   // tests: the lane that takes this unit of the next queued job reports a failure instead of solving it
     bool is_lane = false;        // this handle is a queue lane of another handle (an engine of its own: stream, buffers, host thread, its own twins)
     LanePool* pool = nullptr;
-    long long q_jobs = 0, q_units_done = 0, q_units_skipped = 0;
+    long long q_jobs = 0, q_units_done = 0, q_units_skipped = 0, q_units_failed = 0;
     std::map<int, QJob*> tickets; int next_ticket = 1;      // tf_submit_* jobs not yet waited for
 };
 
@@ -1420,7 +1420,7 @@ void lane_worker(tf_handle* owner, LanePool* pool, tf_handle* lane)
         bool last;
         {
             std::lock_guard<std::mutex> lk(pool->m);
-            if (skip) ++owner->q_units_skipped; else ++owner->q_units_done;
+            if (skip) ++owner->q_units_skipped; else if (rc != TF_OK) ++owner->q_units_failed; else ++owner->q_units_done;
             if (!skip && rc != TF_OK) {
                 if (j->rc == TF_OK) {
                     j->rc = rc;
@@ -1884,11 +1884,11 @@ TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
     else if (n == "coop_rearms") { v = 0; for (auto* t : all) v += t->coop_rearms; }
     else if (n == "coop_cooldown") { v = 0; for (auto* t : all) v = v > t->coop_cooldown ? v : t->coop_cooldown; }
     else if (n == "queue_jobs") v = h->q_jobs;
-    else if (n == "queue_units_done" || n == "queue_units_skipped" || n == "queue_outstanding" || n == "queue_lanes") {
+    else if (n == "queue_units_done" || n == "queue_units_skipped" || n == "queue_units_failed" || n == "queue_outstanding" || n == "queue_lanes") {
         v = 0;
         if (h->pool) {
             std::lock_guard<std::mutex> lk(h->pool->m);
-            v = n == "queue_units_done" ? h->q_units_done : n == "queue_units_skipped" ? h->q_units_skipped : n == "queue_outstanding" ? h->pool->outstanding : (long long)h->pool->lanes.size();
+            v = n == "queue_units_done" ? h->q_units_done : n == "queue_units_skipped" ? h->q_units_skipped : n == "queue_units_failed" ? h->q_units_failed : n == "queue_outstanding" ? h->pool->outstanding : (long long)h->pool->lanes.size();
         }
     }
     else if (n == "experimental") {

@@ -397,67 +397,6 @@ class DenseFlow:
         _lib.check(self._L.tf_comm_wait(self._h, int(ticket)), self._h, "tf_comm_wait")
 
 
-class EnginePool:
-    """Throughput mode: `engines` DenseFlow engines on one GPU that take whole calls in turn, each from its own host thread, so that
-    the tail of one batch (few pairs still iterating, the fine pyramid levels done) overlaps the start of the next.  On an MI355X
-    three DualTVL1 engines solve a stream of 128-pair batches 7-10 % faster than one engine that splits every batch over two lanes
-    and joins them at its end (bench.py `--in-flight`, tools/pipelined_steps.py); results are the single engine's, bit for bit.
-    DeepFlow gains nothing (its solver launches take the whole chip).
-
-        pool = EnginePool(3, max_batch=128)
-        futures = [pool.submit("calc_batch", study) for study in studies]      # any DenseFlow method, same arguments
-        flows = [f.result() for f in futures]
-
-    Parameter setters go to every engine: pool.setLambda(0.15)."""
-
-    def __init__(self, engines=3, **engine_kwargs):
-        from concurrent.futures import ThreadPoolExecutor
-        import queue
-        self.engines = []
-        try:
-            for _ in range(max(1, int(engines))):
-                e = DenseFlow(**engine_kwargs)
-                if int(engines) > 1:
-                    e.set_tuning("lanes", 1)                 # the engines are the lanes
-                self.engines.append(e)
-        except BaseException:
-            self.close()
-            raise
-        self._idle = queue.Queue()
-        for e in self.engines:
-            self._idle.put(e)
-        self._threads = ThreadPoolExecutor(len(self.engines))
-
-    def submit(self, method, *args, **kwargs):
-        """Future of engine.<method>(*args, **kwargs) on the next idle engine."""
-        def run():
-            e = self._idle.get()
-            try:
-                return getattr(e, method)(*args, **kwargs)
-            finally:
-                self._idle.put(e)
-        return self._threads.submit(run)
-
-    def __getattr__(self, name):
-        if name.startswith("set") and name[3:] in DenseFlow._SETTERS:
-            return lambda v: [getattr(e, name)(v) for e in self.engines][-1]
-        raise AttributeError(name)
-
-    def close(self):
-        th = self.__dict__.pop("_threads", None)
-        if th is not None:
-            th.shutdown(wait=True)
-        for e in self.__dict__.get("engines", []):
-            e.close()
-        self.engines = []
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-
-
 def createOptFlow_DeepFlow(device_id=0, **kw):
     """Name-compatible factory for cv2.optflow.createOptFlow_DeepFlow() (reference :568)."""
     return DenseFlow(device_id=device_id, algo="deepflow", **kw)

@@ -110,76 +110,77 @@ def test_limiter_is_derived_from_counter_records(tmp_path, monkeypatch):
     assert bench.classify_limiter("k_z", 0.45)[0].startswith("unclassified")          # another build's counters are not used
 
 
-def _fake_run(E, first, n, collectives, fail_at=None, seed=0):
-    """run_steps_in_flight with fake solves (random short sleeps) and recorded collectives; returns the event log."""
-    import random
-    import threading
-    import time
+def _fake_run(E, first, n, collectives, fail_at=None, nbuf=None):
+    """run_steps_pipelined with fake submits / collects and recorded collectives; returns (stats, log, pending buffers)."""
     import bench
-    rnd = random.Random(seed)
-    delays = {k: rnd.uniform(0.0005, 0.004) for k in range(first, first + n)}
-    log, lock = [], threading.Lock()
-    pending = set()
+    nbuf = nbuf or E + 1
+    log, pending, running = [], set(), set()
 
-    def solve(k):
-        key = (k % E, (k // E) & 1)
-        with lock:
-            log.append(("solve+", k, key, threading.get_ident()))
-            assert key not in pending, f"step {k} solves into buffer {key} while its all-gather is still pending"
-        time.sleep(delays[k])
-        if fail_at is not None and k == fail_at:
+    def submit(k, buf):
+        assert buf == k % nbuf
+        assert buf not in pending, f"step {k} is solved into buffer {buf} while its all-gather is still pending"
+        assert buf not in running, f"step {k} is solved into buffer {buf} while an earlier step is still writing it"
+        assert len(running) < E, "more steps in flight than asked for"
+        running.add(buf)
+        log.append(("submit", k, buf))
+        if E == 1:                                         # the synchronous form: submit is the solve
+            if k == fail_at:
+                running.discard(buf)
+                raise RuntimeError(f"injected failure in step {k}")
+            running.discard(buf)
+            return {"k": k}
+        return ("ticket", k, buf)
+
+    def collect(hd):
+        if E == 1:
+            return hd
+        _, k, buf = hd
+        running.discard(buf)
+        log.append(("collect", k, buf))
+        if k == fail_at:
             raise RuntimeError(f"injected failure in step {k}")
-        with lock:
-            log.append(("solve-", k, key, threading.get_ident()))
         return {"k": k}
 
-    def issue(key):
-        with lock:
-            log.append(("issue", None, key, threading.get_ident()))
-            assert key not in pending
-            pending.add(key)
+    def issue(buf):
+        assert buf not in pending and buf not in running
+        pending.add(buf)
+        log.append(("issue", None, buf))
 
-    def retire(key):
-        time.sleep(0.0005)
-        with lock:
-            log.append(("retire", None, key, threading.get_ident()))
-            pending.discard(key)
-    stats = bench.run_steps_in_flight(first, n, E, solve, issue if collectives else None, retire if collectives else None)
-    return stats, log, pending
+    def retire(buf):
+        pending.discard(buf)
+        log.append(("retire", None, buf))
+    stats = bench.run_steps_pipelined(first, n, E, nbuf, submit, collect, issue if collectives else None, retire if collectives else None)
+    return stats, log, pending, running
 
 
 @pytest.mark.parametrize("E,first,n", [(1, 0, 5), (2, 1, 9), (3, 5, 20), (3, 0, 2), (4, 3, 13)])
 @pytest.mark.parametrize("collectives", [False, True], ids=["one-rank", "with-collectives"])
-def test_steps_in_flight_order_and_buffer_safety(E, first, n, collectives):
-    """The N > 1 form of the timed loop cannot run on the hardware here (one GPU): its logic is pinned with fake solves.  Every step is
-    solved once, by engine k % E on that engine's thread; collectives are issued by the caller's thread in step order; no solve writes a
-    buffer whose all-gather has not been retired (asserted inside the fakes); the last E all-gathers (E = 1: two, one per flow buffer) are left for the caller's drain."""
-    import threading
-    stats, log, pending = _fake_run(E, first, n, collectives, seed=E * 100 + n)
-    assert [s["k"] for s in stats] == list(range(first, first + n))
-    solved = [e for e in log if e[0] == "solve+"]
-    assert sorted(e[1] for e in solved) == list(range(first, first + n))
-    by_engine = {}
-    for _, k, key, tid in solved:
-        assert key == (k % E, (k // E) & 1)
-        by_engine.setdefault(k % E, set()).add(tid)
-    assert all(len(t) == 1 for t in by_engine.values())                    # one host thread per engine
+def test_pipelined_steps_order_and_buffer_safety(E, first, n, collectives):
+    """The N > 1 form of the timed loop cannot run on the hardware here (one GPU): its logic is pinned with fakes.  Every step is submitted
+    once, in order, with at most E in flight; collectives are issued in step order, each right after its step has been collected; no step
+    is solved into a buffer that is still being gathered or written (asserted inside the fakes); the last min(n, E + 1) all-gathers are
+    left for the caller's drain."""
+    stats, log, pending, running = _fake_run(E, first, n, collectives)
+    assert [s["k"] for s in stats] == list(range(first, first + n)) and not running
+    assert [e[1] for e in log if e[0] == "submit"] == list(range(first, first + n))
     if E > 1:
-        assert threading.get_ident() not in set().union(*by_engine.values())
+        assert [e[1] for e in log if e[0] == "collect"] == list(range(first, first + n))
+        # a step is collected only when E are in flight (or at the end): the overlap is real
+        pos = {("submit", e[1]): i for i, e in enumerate(log) if e[0] == "submit"}
+        pos.update({("collect", e[1]): i for i, e in enumerate(log) if e[0] == "collect"})
+        for k in range(first, first + n - E):
+            assert pos[("submit", k + E - 1)] < pos[("collect", k)] < pos[("submit", k + E)]
     if collectives:
-        issued = [e for e in log if e[0] == "issue"]
-        assert [e[2] for e in issued] == [(k % E, (k // E) & 1) for k in range(first, first + n)]      # step order
-        assert all(e[3] == threading.get_ident() for e in log if e[0] in ("issue", "retire"))          # the caller's thread only
-        assert len(pending) == min(n, 2 if E == 1 else E)          # what the caller's drain retires (E = 1: both flow buffers)
+        assert [e[2] for e in log if e[0] == "issue"] == [k % (E + 1) for k in range(first, first + n)]      # step order
+        assert len(pending) == min(n, E + 1)
     else:
         assert not [e for e in log if e[0] in ("issue", "retire")]
 
 
+@pytest.mark.parametrize("E", [1, 3])
 @pytest.mark.parametrize("collectives", [False, True])
-def test_steps_in_flight_failure_comes_home(collectives):
-    """A solve that raises must neither hang the caller nor the other engines' threads."""
-    import threading
-    before = threading.active_count()
+def test_pipelined_steps_failure_leaves_nothing_in_flight(E, collectives):
+    """A step that fails must not leave later steps submitted and uncollected."""
+    import bench  # noqa: F401
     with pytest.raises(RuntimeError, match="injected failure in step 9"):
-        _fake_run(3, 2, 15, collectives, fail_at=9)
-    assert threading.active_count() == before
+        _fake_run(E, 2, 15, collectives, fail_at=9)

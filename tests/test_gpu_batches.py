@@ -168,18 +168,3 @@ def test_one_wave_per_strip_forms_in_mixed_batches(oracle, variant, n, H, W, par
     finally:
         eng.close()
 
-
-def test_engine_pool_gives_the_single_engines_flows(engine, oracle):
-    """Throughput mode: three engines take whole batches in turn from three host threads; every batch's flows (and iteration counts, through
-    the oracle) are what one engine gives, in whatever order the batches finish."""
-    import tee_optical_flow_amd as T
-    from tee_optical_flow_amd.synth import speckle_pairs
-    batches = [speckle_pairs(range(40 * k, 40 * k + n), 96, 128) for k, n in enumerate([5, 9, 3, 7, 9, 4, 6])]
-    with T.EnginePool(3, max_batch=9) as pool:
-        pool.setLambda(0.15)
-        futs = [pool.submit("calc_pairs", I0s, I1s) for I0s, I1s in batches]
-        got = [f.result() for f in futs]
-        assert all(e.getLambda() == 0.15 for e in pool.engines)
-    for (I0s, I1s), g in zip(batches, got):
-        assert np.array_equal(g, engine.calc_pairs(I0s, I1s))
-    assert np.array_equal(got[1][8], oracle.tvl1_calc(batches[1][0][8], batches[1][1][8]))

@@ -39,6 +39,16 @@ try:
     raise SystemExit("an unknown ticket must be refused")
 except T.OpticalFlowCalculationError:
     pass
+# a second engine produces the flows on its lanes (two sub-batches, a submitted job); the communicator handle never solves.  The order is
+# the host's (include/teeflow.h): tf_wait has returned -> every lane has drained -> the all-gather may be issued at once
+prod = T.DenseFlow(device_id=0, max_batch=2)
+fr = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)
+pf = torch.zeros_like(ref); gat = torch.zeros_like(ref)
+tk = prod.submit_pairs_device(fr.data_ptr(), fr.data_ptr() + 4 * 96 * 128, 4, 96, 128, pf.data_ptr())
+prod.wait(tk)
+eng.comm_wait(eng.allgather(pf.data_ptr(), pf.numel(), gat.data_ptr()))
+assert prod.counter("queue_units_done") == 2 and torch.equal(pf, ref) and torch.equal(gat, ref)
+prod.close()
 # single-process form (ncclCommInitAll + grouped calls) on one device
 eng2 = T.DenseFlow(device_id=0, max_batch=4)
 L = _lib.load()
@@ -60,8 +70,8 @@ def test_library_rccl_allgather_one_rank(tmp_path):
     assert r.returncode == 0 and "comm ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("extra", [[], ["--steps", "8", "--warmup", "2", "--in-flight", "3"], ["--steps", "3", "--in-flight", "1"]],
-                         ids=["default", "8-steps-3-in-flight", "joined-steps"])
+@pytest.mark.parametrize("extra", [[], ["--steps", "8", "--warmup", "2", "--in-flight", "3"], ["--steps", "3", "--batch", "4"]],
+                         ids=["default", "8-steps-3-in-flight", "one-sub-batch-per-step"])
 def test_bench_gpus_2_starts_its_own_ranks(extra):
     """`python bench.py --gpus 2` from a plain shell (no torchrun, WORLD_SIZE unset) must start its ranks
     itself and print ONE line for the job.  Rehearsed on the one GPU a test box has: gloo rendezvous, both ranks on cuda:0,
@@ -70,7 +80,7 @@ def test_bench_gpus_2_starts_its_own_ranks(extra):
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
-                        "--batch", "4", "--size", "96", "--steps", "2", "--warmup", "1", "--no-deepflow", "--no-cpu-baseline",
+                        "--batch", "10", "--sub-batch", "4", "--size", "96", "--steps", "2", "--warmup", "1", "--no-deepflow", "--no-cpu-baseline",
                         "--no-profile", "--steps-only"] + extra, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -78,7 +88,11 @@ def test_bench_gpus_2_starts_its_own_ranks(extra):
     d = json.loads(lines[0])
     nsteps = int(extra[extra.index("--steps") + 1]) if "--steps" in extra else 2
     assert d["n_gpus"] == 2 and d["steps"] == nsteps and d["scaling"] == "weak" and d["value"] > 0
-    # steps in flight (engines taking whole steps in turn): the collectives are still issued in step order by one thread per rank
-    assert d["config"]["steps_in_flight"] == (1 if "joined-steps" in os.environ.get("PYTEST_CURRENT_TEST", "") else 3)
+    # every step is ONE call of the boundary (10 pairs = three sub-batches on the library's lanes, or one sub-batch); with --in-flight 3 the
+    # steps are submitted without waiting and the collectives are still issued in step order, each after its step has been collected
+    cur = os.environ.get("PYTEST_CURRENT_TEST", "")
+    assert d["config"]["steps_in_flight"] == (3 if "3-in-flight" in cur else 1) and d["config"]["calls_per_step"] == 1
+    assert d["config"]["sub_batches_per_step"] == (1 if "one-sub-batch" in cur else 3)
+    assert d["config"]["library_queue_lanes"] == (0 if "one-sub-batch" in cur else 3)
     assert "all_gather" in d["collective"] and d["allgather_checksums_match"] is True
     assert d["config"]["parallelism"] == "pair-sharded x2"

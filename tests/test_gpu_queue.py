@@ -80,7 +80,7 @@ def test_a_failing_sub_batch_drains_every_lane_before_the_call_returns(oracle):
         # units 0 and 2 were running on the other lanes and finished; unit 3 was never started; nothing is queued or in flight
         assert eng.counter("queue_outstanding") == 0
         assert eng.counter("queue_units_done") - done0 + eng.counter("queue_units_skipped") == 3
-        assert eng.counter("queue_units_skipped") >= 1
+        assert eng.counter("queue_units_skipped") >= 1 and eng.counter("queue_units_failed") == 1
         again = np.array(eng.calc_pairs(I0s, I1s))                         # the handle is whole: same bits as before
         assert np.array_equal(again, good) and np.array_equal(eng.last_iters(), it)
         eng.set_tuning("queue_test_fail_unit", 3)                          # the last unit fails: everything else has been solved

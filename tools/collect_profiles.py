@@ -54,7 +54,7 @@ def sq_summary(tag, algo, kernel):
     sys.path.insert(0, ROOT)
     from bench import kernel_source_fingerprint
     out = {"kernel": kernel, "source_fingerprint": kernel_source_fingerprint(), "dispatches": n, "command": f"tools/pmc_sq.sh {tag} {algo}  (rocprofv3 --pmc <<=5 counters per pass> --kernel-include-regex ... -- "
-                                                           "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --steps-only --in-flight 1 --lanes 1 --no-deepflow" + (" --algo deepflow --batch 128)" if algo == "deepflow" else ")"),
+                                                           "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --steps-only --in-flight 1 --lanes 1 --no-deepflow --batch 128" + (" --algo deepflow)" if algo == "deepflow" else ")"),
            "units": "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
            "totals": {k: tot[k] for k in sorted(tot)}, "per_dispatch_mean": {k: tot[k] / cnt[k] for k in sorted(tot)},
            "totals_all_dispatches": {k: tot_all[k] for k in sorted(tot_all)}}

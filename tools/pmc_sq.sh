@@ -12,8 +12,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 [ -f $OUT/../counters_list.txt ] || rocprofv3 -L > $OUT/../counters_list.txt 2>&1
-EXTRA=""
-[ "$ALGO" = "deepflow" ] && EXTRA="--batch 128"
+EXTRA="--batch 128"          # one sub-batch on one lane: exclusive launches (the default 384-pair step runs three lanes at once)
 [ -n "${TUNING:-}" ] && EXTRA="$EXTRA --tuning $TUNING"          # engine knobs for an experiment: TUNING=sor_fuse=7 bash tools/pmc_sq.sh x deepflow
 pass() {
   local name=$1; shift

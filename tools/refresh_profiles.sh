@@ -8,7 +8,7 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/collect_profiles.py <tag> condenses them into profiles/.
 # usage: bash tools/refresh_profiles.sh <round-tag, e.g. r03>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -30,10 +30,10 @@ python3 tools/collect_profiles.py $TAG $GRAFT_REPO_ROOT/gpurun_out/collected_$TA
 [ -f gpurun_out/collected_$TAG/${TAG}_sq_counters.json ] && cp gpurun_out/collected_$TAG/${TAG}_sq_counters.json profiles/
 cd /tmp
 run_stats default
-run_stats lanes1 --in-flight 1 --lanes 1 --no-cpu-baseline
+run_stats lanes1 --batch 128 --lanes 1 --no-cpu-baseline
 # one algorithm per profiled command (the combined tables need arithmetic to read per-algorithm shares)
-run_stats tvl1_lanes1 --in-flight 1 --lanes 1 --no-cpu-baseline --no-deepflow
-run_stats deepflow_lanes1 --in-flight 1 --lanes 1 --no-cpu-baseline --algo deepflow
+run_stats tvl1_lanes1 --batch 128 --lanes 1 --no-cpu-baseline --no-deepflow
+run_stats deepflow_lanes1 --lanes 1 --no-cpu-baseline --algo deepflow
 cd $GRAFT_REPO_ROOT
 timeout -k 10 200 python3 tools/launch_profile.py --batch 64 > $OUT/${TAG}_launch_profile_b64.txt 2>&1; echo "launch_profile rc=$?"
 [ -x tools/microbench/ablate_probe ] && (cd tools/microbench && timeout -k 10 200 ./ablate_probe > $OUT/${TAG}_ablate_probe.txt 2>&1; echo "ablate rc=$?")
