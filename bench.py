@@ -35,6 +35,11 @@ import time
 
 import numpy as np
 
+# Before anything initialises HIP: a roomier pool of hardware queues than HIP's default 4, so that the engine's three lanes, their copy
+# streams and torch's streams do not share one (streams that share a hardware queue are serialised; the library also probes for this
+# when it makes its lanes -- `streams_serialised` in the line below says if it had to give up).  A caller's own setting is left alone.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -464,6 +469,8 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     last_buf = (warmup + steps - 1) % NBUF
     last_flow = flows[last_buf]
     queue_lanes = eng.counter("queue_lanes")
+    lane_streams = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_tried_and_dropped": eng.counter("stream_retries"),
+                    "lanes_serialised_on_a_shared_hardware_queue": bool(eng.counter("streams_serialised"))}
     gather_ok = None
     if world > 1:
         # every rank's shard must have arrived intact everywhere: compare checksums of the gathered segments with the
@@ -661,7 +668,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                        "calls_per_step": 1, "boundary_call": ("tf_calc_pairs_device (synchronous)" if E == 1 else f"tf_submit_pairs_device / tf_wait, {E} steps in flight"),
                        "sub_batch_pairs": SUB, "sub_batches_per_step": len(subs),
                        # what overlaps inside the library (include/teeflow.h "Sub-batches and lanes"): lanes that take whole sub-batches from a queue
-                       "steps_in_flight": E, "library_queue_lanes": queue_lanes if B > SUB or E > 1 else 0,
+                       "steps_in_flight": E, "library_queue_lanes": queue_lanes if B > SUB or E > 1 else 0, "lane_streams": lane_streams,
                        "lanes_per_sub_batch_call": a.lanes if B <= SUB and E == 1 else (a.lanes if algo != "TVL1" else 1)},
             # data-independent rate of the whole job: executed pixel-iterations (pixel-sweeps) per second of the timed region
             ("px_iterations_per_s" if algo == "TVL1" else "px_sweeps_per_s"): world * acc["timed_iter_bytes"] / unit_bytes / dt,

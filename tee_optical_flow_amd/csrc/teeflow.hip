@@ -29,6 +29,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <deque>
 #include <string>
 #include <atomic>
@@ -40,6 +41,12 @@
 #include <vector>
 
 #define TF_API extern "C" __attribute__((visibility("default")))
+
+// HIP's default of 4 hardware queues per process makes the streams of a process share them, and work of streams that share one is
+// serialised (see streams_concurrent below).  The lanes probe for streams that run beside each other; a roomier pool makes the search
+// trivial and also keeps the lanes' copy streams off each other's queues.  Takes effect only if this library is loaded before the HIP
+// runtime initialises (it reads the variable once); a value the caller has set is left alone.
+__attribute__((constructor)) static void tf_hw_queue_default() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 namespace {
 
@@ -193,6 +200,8 @@ struct tf_handle : TfKnobs {
     LanePool* pool = nullptr;
     long long q_jobs = 0, q_units_done = 0, q_units_skipped = 0, q_units_failed = 0;
     std::map<int, QJob*> tickets; int next_ticket = 1;      // tf_submit_* jobs not yet waited for
+    int stream_retries = 0;      // streams made and dropped while looking for lane / twin streams that run beside each other (give_concurrent_stream)
+    int streams_serialised = 0;  // 1: a lane or twin had to keep a stream that shares a hardware queue with another one's
 };
 
 
@@ -1298,6 +1307,72 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     return TF_OK;
 }
 
+// ---- do two streams run beside each other? --------------------------------------------------------------------------------------
+// HIP multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and work of two streams that share
+// one is serialised.  A lane exists to run BESIDE the others: with two lanes' streams on one hardware queue the queue form measured
+// 2580 instead of 2830 pairs/s (and the two-lane split 2170 instead of 2630 with GPU_MAX_HW_QUEUES=2).  Which queue a new stream lands
+// on depends on every other stream the process holds (torch's, copy streams, idle handles), so it is probed, not assumed: a kernel on
+// stream A waits (bounded: ~0.5 ms) for a flag that a kernel on stream B sets; it sees the flag only if B's kernel could start while
+// A's was running.
+__global__ void k_probe_wait(int* flag, int* seen, long long ticks)
+{
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();       // 100 MHz
+    int v = 0;
+    while (!(v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && (long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    *seen = v;
+}
+__global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 1 = b's kernel ran while a's was running, 0 = it did not (shared hardware queue), -1 = the probe itself failed
+int streams_concurrent(hipStream_t a, hipStream_t b)
+{
+    if (a == b) return 0;
+    int* d = nullptr;
+    if (hipMalloc(&d, 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    int seen = -1;
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(int), a);
+    if (e == hipSuccess) e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, d, d + 1, 50000LL);
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, d);
+        e = hipStreamSynchronize(b);
+        if (e == hipSuccess) e = hipStreamSynchronize(a);
+        if (e == hipSuccess) e = hipMemcpy(&seen, d + 1, sizeof(int), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return seen == 1 ? 1 : 0;
+}
+
+// Give handle `t` a solve stream that runs beside every stream in `others` (new streams are tried until one does; the rejected ones are
+// kept until the search is over, so that the next one lands elsewhere, then destroyed).  Returns true when t's stream is concurrent
+// with all of them; false leaves the last stream tried (work still runs, serialised with one of the others).
+bool give_concurrent_stream(tf_handle* t, const std::vector<hipStream_t>& others, int* retries)
+{
+    auto ok_with_all = [&](hipStream_t s) {
+        for (hipStream_t o : others) if (streams_concurrent(o, s) == 0) return false;
+        return true;
+    };
+    if (ok_with_all(t->own_stream)) return true;
+    std::vector<hipStream_t> rejected;
+    bool ok = false;
+    for (int k = 0; k < 8 && !ok; ++k) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (retries) ++*retries;
+        if (ok_with_all(s)) {
+            (void)hipStreamSynchronize(t->own_stream);
+            rejected.push_back(t->own_stream);
+            if (t->stream == t->own_stream) t->stream = s;
+            t->own_stream = s;
+            ok = true;
+        } else rejected.push_back(s);
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    return ok;
+}
+
 void merge_stats(tf_stats* st, const tf_stats& sb)
 {
     st->ms_total = std::max(st->ms_total, sb.ms_total);
@@ -1341,6 +1416,9 @@ int calc_split(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         int rc = h->P.algo == TF_ALGO_DEEPFLOW ? tf_create_deepflow(&h->DP, h->dev, &t) : tf_create(&h->P, h->dev, &t);
         if (rc) return fail(h, rc, "creating lane %d failed: %s", (int)h->twins.size() + 2, tf_last_error(nullptr));
         t->is_twin = true;
+        std::vector<hipStream_t> others{h->own_stream};
+        for (tf_handle* o : h->twins) others.push_back(o->own_stream);
+        if (!give_concurrent_stream(t, others, &h->stream_retries)) h->streams_serialised = 1;
         h->twins.push_back(t);
     }
     const size_t npx = (size_t)H * W, fpx = npx * (h->src_f32 ? 4 : 1);      // fpx in bytes
@@ -1481,6 +1559,9 @@ int pool_ensure(tf_handle* h)
             return fail(h, rc, "creating queue lane %d failed: %s", k + 1, tf_last_error(nullptr));
         }
         t->is_lane = true;
+        std::vector<hipStream_t> others;
+        for (tf_handle* o : pool->lanes) others.push_back(o->own_stream);
+        if (!give_concurrent_stream(t, others, &h->stream_retries)) h->streams_serialised = 1;
         pool->lanes.push_back(t);
     }
     h->pool = pool;
@@ -1884,6 +1965,8 @@ TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
     else if (n == "coop_rearms") { v = 0; for (auto* t : all) v += t->coop_rearms; }
     else if (n == "coop_cooldown") { v = 0; for (auto* t : all) v = v > t->coop_cooldown ? v : t->coop_cooldown; }
     else if (n == "queue_jobs") v = h->q_jobs;
+    else if (n == "stream_retries") { v = h->stream_retries; if (h->pool) for (auto* l : h->pool->lanes) v += l->stream_retries; }
+    else if (n == "streams_serialised") { v = h->streams_serialised; if (h->pool) for (auto* l : h->pool->lanes) v |= l->streams_serialised; }
     else if (n == "queue_units_done" || n == "queue_units_skipped" || n == "queue_units_failed" || n == "queue_outstanding" || n == "queue_lanes") {
         v = 0;
         if (h->pool) {

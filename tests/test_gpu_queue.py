@@ -126,29 +126,47 @@ def test_jobs_in_flight_are_collected_in_any_order(oracle):
         eng.close()
 
 
+DEVICE_JOBS = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, ROOT)
+import tee_optical_flow_amd as T
+from tests.test_gpu_batches import _mixed_pairs
+I0s, I1s = _mixed_pairs(24, 64, 88, seed0=70)
+dev = torch.device("cuda", 0)
+fr = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)
+p0, p1 = fr.data_ptr(), fr.data_ptr() + 24 * 64 * 88
+out = [torch.zeros((24, 64, 88, 2), dtype=torch.float32, device=dev) for _ in range(4)]
+eng = T.DenseFlow(device_id=0, max_batch=8)
+try:
+    eng.calc_pairs_device(p0, p1, 24, 64, 88, out[0].data_ptr())
+    ref = out[0].cpu().numpy()
+    assert np.array_equal(ref, np.array(eng.calc_pairs(I0s, I1s)))
+    tk = [eng.submit_pairs_device(p0, p1, 24, 64, 88, out[k].data_ptr(), scale=float(k)) for k in (1, 2, 3)]
+    for k, t in zip((1, 2, 3), tk):
+        st = eng.wait(t)
+        assert st["n_pairs"] == 24
+        assert np.array_equal(out[k].cpu().numpy(), ref * np.float32(k))
+    for k in (1, 2, 3):                                                # closing with jobs queued: the lanes finish them first
+        eng.submit_pairs_device(p0, p1, 24, 64, 88, out[k].data_ptr())
+finally:
+    eng.close()
+torch.cuda.synchronize()
+for k in (1, 2, 3):
+    assert np.array_equal(out[k].cpu().numpy(), ref)
+print("device jobs ok")
+"""
+
+
 def test_device_jobs_in_flight_and_close_with_jobs_queued():
-    import torch
-    I0s, I1s = _mixed(24, 64, 88, seed0=70)
-    dev = torch.device("cuda", 0)
-    fr = torch.from_numpy(np.concatenate([I0s, I1s])).to(dev)
-    p0, p1 = fr.data_ptr(), fr.data_ptr() + 24 * 64 * 88
-    out = [torch.zeros((24, 64, 88, 2), dtype=torch.float32, device=dev) for _ in range(4)]
-    eng = _engine(8)
-    try:
-        eng.calc_pairs_device(p0, p1, 24, 64, 88, out[0].data_ptr())
-        ref = out[0].cpu().numpy()
-        tk = [eng.submit_pairs_device(p0, p1, 24, 64, 88, out[k].data_ptr(), scale=float(k)) for k in (1, 2, 3)]
-        for k, t in zip((1, 2, 3), tk):
-            st = eng.wait(t)
-            assert st["n_pairs"] == 24
-            assert np.array_equal(out[k].cpu().numpy(), ref * np.float32(k))
-        for k in (1, 2, 3):                                                # closing with jobs queued: the lanes finish them first
-            eng.submit_pairs_device(p0, p1, 24, 64, 88, out[k].data_ptr())
-    finally:
-        eng.close()
-    torch.cuda.synchronize()
-    for k in (1, 2, 3):
-        assert np.array_equal(out[k].cpu().numpy(), ref)
+    """tf_submit_pairs_device on torch tensors (a child process with torch imported first: the engine and torch must share one HIP runtime,
+    and in the pytest process the engine has usually initialised HIP before torch is touched)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", DEVICE_JOBS.replace("ROOT", repr(root))], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "device jobs ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_deepflow_through_the_queue(oracle):

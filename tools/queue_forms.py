@@ -27,18 +27,27 @@ def main():
     ap.add_argument("--algo", default="TVL1")
     ap.add_argument("--tuning", default="")
     ap.add_argument("--skip-b", action="store_true")
+    ap.add_argument("--no-pool", action="store_true")
+    ap.add_argument("--distinct", action="store_true", help="384 DISTINCT pairs (seeds 0..383, what bench.py solves per step) instead of the same 128 three times: "
+                                                            "the sub-batches of a call then differ in length")
     a = ap.parse_args()
     from bench import make_inputs
     B, S = 128, a.size
     calls = [int(c) for c in a.calls.split(",") if c]
     PM = max(calls + [B])
     I0s, I1s = make_inputs(list(range(B)), S, S, allow_pool=False)
+    if a.distinct:
+        D0, D1 = make_inputs(list(range(3 * B)), S, S, allow_pool=not a.no_pool)
     import torch
     import tee_optical_flow_amd as T
     dev = torch.device("cuda", 0)
     reps = (PM + B - 1) // B
     # [I0 x reps | I1 x reps]: every 128-pair slice is the same 128 pairs, so every form does the same work per pair
-    frames = torch.from_numpy(np.concatenate([np.tile(I0s, (reps, 1, 1)), np.tile(I1s, (reps, 1, 1))])).to(dev)
+    if a.distinct:                                                  # pairs k, k + 384, ... are the same pair
+        big0, big1 = np.tile(D0, (-(-reps // 3), 1, 1))[:reps * B], np.tile(D1, (-(-reps // 3), 1, 1))[:reps * B]
+    else:
+        big0, big1 = np.tile(I0s, (reps, 1, 1)), np.tile(I1s, (reps, 1, 1))
+    frames = torch.from_numpy(np.concatenate([big0, big1])).to(dev)
     p0, p1 = frames.data_ptr(), frames.data_ptr() + reps * B * S * S
     big = torch.empty((reps * B, S, S, 2), dtype=torch.float32, device=dev)
     ring = [torch.empty((B, S, S, 2), dtype=torch.float32, device=dev) for _ in range(8)]
@@ -56,10 +65,13 @@ def main():
         e.set_tuning("lanes", 1)
     ref = None
 
+    NSUB = 3 if a.distinct else 1
+    off = lambda k: (k % NSUB) * B * S * S
+
     def form_a(steps):
         for k in range(steps):
-            one.calc_pairs_device(p0, p1, B, S, S, ring[k & 1].data_ptr())
-        return ring[(steps - 1) & 1]
+            one.calc_pairs_device(p0 + off(k), p1 + off(k), B, S, S, ring[k % NSUB].data_ptr())
+        return ring[0]
 
     def form_b(steps):
         nxt, lock = [0], threading.Lock()
@@ -70,7 +82,9 @@ def main():
                     k = nxt[0]; nxt[0] += 1
                 if k >= steps:
                     return
-                three[i].calc_pairs_device(p0, p1, B, S, S, ring[i].data_ptr())
+                three[i].calc_pairs_device(p0 + off(k), p1 + off(k), B, S, S, ring[3 + i].data_ptr())
+                if k % NSUB == 0:
+                    ring[0].copy_(ring[3 + i])
         th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
         for t in th:
             t.start()
@@ -84,8 +98,9 @@ def main():
             if k - E >= 0:
                 one.wait(tk.pop(k - E))
             if k < steps:
-                tk[k] = one.submit_pairs_device(p0, p1, B, S, S, ring[k % (E + 1)].data_ptr())
-        return ring[(steps - 1) % (E + 1)]
+                tk[k] = one.submit_pairs_device(p0 + off(k), p1 + off(k), B, S, S, ring[k % (E + 1)].data_ptr())
+        last0 = max(k for k in range(steps) if k % NSUB == 0)
+        return ring[last0 % (E + 1)]
 
     def form_d(steps, P):
         n = max(1, steps * B // P)
@@ -120,8 +135,10 @@ def main():
             print(f"  c  one engine, tf_submit 128-pair jobs, {E} in flight   : {a.steps * B / dt:7.1f} pairs/s  identical {np.array_equal(f.cpu().numpy(), ref)}")
         for P in calls:
             dt, (f, n) = timed(form_d, a.steps, P)
-            same = np.array_equal(f.cpu().numpy(), ref) and np.array_equal(big[P - B:P].cpu().numpy(), ref)
+            same = np.array_equal(f.cpu().numpy(), ref) and (a.distinct or np.array_equal(big[P - B:P].cpu().numpy(), ref))
             print(f"  d  one engine, ONE synchronous call per {P:5d} pairs   : {n / dt:7.1f} pairs/s  identical {same}")
+    print(f"  lane / twin streams: tried and dropped {one.counter('stream_retries')}, serialised on a shared hardware queue: {bool(one.counter('streams_serialised'))}, "
+          f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
     one.close()
     for e in three:
         e.close()
