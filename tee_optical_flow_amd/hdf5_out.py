@@ -20,18 +20,17 @@ def _workers():
     return max(1, min(16, n))
 
 
-def create_gzip9(f, name, data, min_parallel_bytes=1 << 20, level=9):
+def create_gzip9(f, name, data, min_parallel_bytes=1 << 20):
     """`f.create_dataset(name, data=data, compression="gzip", compression_opts=9)` (reference :405-472) with the deflate
     work spread over threads: same dataset for any reader (dtype, shape, h5py's auto chunk shape, filter pipeline, values),
     but the chunks are compressed with zlib level 9 in a thread pool (zlib releases the GIL) and handed to HDF5 with
     `write_direct_chunk`.  gzip-9 of a study's float16 flow is the slowest step of process_video once the flow itself
-    takes milliseconds (63 MB: 2.4 s in h5py, 0.4 s here on 8 cores).
-    `level` (9 = the reference's bytes) only changes how hard zlib tries on the chunks handed over; the dataset still carries the gzip
-    filter with option 9 and reads back the same values.  0 stores the chunks uncompressed inside valid deflate streams."""
+    takes milliseconds (63 MB: 2.4 s in h5py, 0.4 s here on 8 cores).  The effort is the reference's, always: the filter header says
+    gzip 9 and the chunk bytes are level-9 deflate streams (round 4's opt-in lower effort left that contract and is gone)."""
     data = np.asarray(data)
     ds = f.create_dataset(name, shape=data.shape, dtype=data.dtype, compression="gzip", compression_opts=9)
     ch = ds.chunks
-    if (data.nbytes < min_parallel_bytes and level == 9) or ch is None or data.ndim == 0 or not hasattr(ds.id, "write_direct_chunk"):
+    if data.nbytes < min_parallel_bytes or ch is None or data.ndim == 0 or not hasattr(ds.id, "write_direct_chunk"):
         ds[...] = data
         return ds
     offsets = list(itertools.product(*[range(0, s, c) for s, c in zip(data.shape, ch)]))
@@ -44,7 +43,7 @@ def create_gzip9(f, name, data, min_parallel_bytes=1 << 20, level=9):
                 full = np.zeros(ch, data.dtype)
                 full[tuple(slice(0, n) for n in blk.shape)] = blk
                 blk = full
-            out.append((off, zlib.compress(np.ascontiguousarray(blk), level)))
+            out.append((off, zlib.compress(np.ascontiguousarray(blk), 9)))
         return out
 
     group = 16
@@ -56,14 +55,9 @@ def create_gzip9(f, name, data, min_parallel_bytes=1 << 20, level=9):
 
 
 def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config,
-                              mode, no_saliency, include_waveforms, save_mask_subset=None, *, echo=None, nframes=None,
-                              flow_deflate_level=None):
+                              mode, no_saliency, include_waveforms, save_mask_subset=None, *, echo=None, nframes=None):
     """`echo` (float16 [N,H,W] = rgb2gray(nparr).astype(float16), reference :400-402) and `nframes` may be handed over instead of
-    `nparr` (process_folder's worker processes: the reader stage makes `echo`, the RGB frames need not travel to the writer).
-    `flow_deflate_level` (None = 9, or the environment's TEEFLOW_FLOW_DEFLATE_LEVEL): zlib effort for the `flow` and `echo` datasets only.
-    Speckle flow cast to float16 barely compresses (68 MB -> 55 MB) and costs zlib ~29 MB/s per core at EVERY level from 1 to 9 -- 9 of the
-    ~9.6 core-seconds a study costs end to end; 0 writes those two datasets as stored deflate blocks (same layout, same filter, same
-    values for every reader, files ~25 % larger) and leaves the study's cost to the solver and the mask stage."""
+    `nparr` (process_folder's worker processes: the reader stage makes `echo`, the RGB frames need not travel to the writer)."""
     try:
         import h5py
     except ImportError as e:  # pragma: no cover
@@ -73,12 +67,8 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
     # that the skip-if-exists rule of process_folder would then take for a finished study.
     tmp_path = f"{save_path}.part{os.getpid()}"
     try:
-        if flow_deflate_level is None:
-            flow_deflate_level = int(os.environ.get("TEEFLOW_FLOW_DEFLATE_LEVEL", "9"))
-        if not 0 <= int(flow_deflate_level) <= 9:
-            raise OpticalFlowError(f"flow_deflate_level must be 0..9, got {flow_deflate_level}")
         _write(h5py, tmp_path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config, mode, no_saliency,
-               include_waveforms, save_mask_subset, echo, nframes, int(flow_deflate_level))
+               include_waveforms, save_mask_subset, echo, nframes)
         os.replace(tmp_path, save_path)
     finally:
         if os.path.exists(tmp_path):
@@ -86,11 +76,11 @@ def save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, metadata, w
 
 
 def _write(h5py, path, flow_arr, nparr, mask_dict, metadata, waveforms, patient_id, heart_rate, config, mode, no_saliency,
-           include_waveforms, save_mask_subset, echo=None, nframes=None, flow_level=9):
+           include_waveforms, save_mask_subset, echo=None, nframes=None):
     nan = float("nan")
     with h5py.File(path, "w") as f:
-        create_gzip9(f, "echo", np.asarray(echo, dtype=np.float16) if echo is not None else rgb2gray(nparr).astype(np.float16), level=flow_level)
-        fd = create_gzip9(f, "flow", np.asarray(flow_arr).astype(np.float16), level=flow_level)
+        create_gzip9(f, "echo", np.asarray(echo, dtype=np.float16) if echo is not None else rgb2gray(nparr).astype(np.float16))
+        fd = create_gzip9(f, "flow", np.asarray(flow_arr).astype(np.float16))
         # missing metadata: same attribute names and float64 type as a complete study, value NaN (units_converted says so)
         fd.attrs["frame_rate"] = nan if metadata["frame_rate"] is None else metadata["frame_rate"]
         fd.attrs["nframes"] = int(nframes) if nframes is not None else nparr.shape[0]

@@ -117,7 +117,7 @@ def _prep_frames(nparr, flipLR):
 def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode="A4C", bkgd_comp="none", flipLR=False,
                   no_saliency=False, OF_algo="TVL1", save_mask_subset=None, include_waveforms=False, waveform_folder=None,
                   config=None, *, nparr=None, metadata=None, patient_id="", heart_rate=0, waveforms=None, flow_model=None,
-                  mask_dict=None, _defer_save=None, flow_deflate_level=None):
+                  mask_dict=None, _defer_save=None):
     """Same positional signature as the reference (:478-483).  Keyword-only extras let a caller inject what the
     offline image cannot provide: `nparr` (frames instead of a DICOM), `metadata`, `mask_dict` (segmentation result),
     `flow_model`.  Returns the float32 flow array [N,H,W,2] that was written."""
@@ -187,7 +187,7 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
             _defer_save(job)                      # process_folder: the writer thread takes it while the next study is solved
         else:
             from .hdf5_out import save_optical_flow_to_hdf5
-            save_optical_flow_to_hdf5(*job, flow_deflate_level=flow_deflate_level)
+            save_optical_flow_to_hdf5(*job)
     return flow_arr
 
 
@@ -373,7 +373,7 @@ def _prepare_study_shm(reader, path, mode, flipLR, config, want_echo):
     return nparr, md, pid, hr, masks_ahead, echo
 
 
-def _save_study_shm(job, echo, nframes, flow_deflate_level=None):
+def _save_study_shm(job, echo, nframes):
     """Writer stage in a worker process: map what arrived as descriptors, write the file, drop the mappings (the owner unlinks)."""
     from .hdf5_out import save_optical_flow_to_hdf5
     blocks = []
@@ -383,7 +383,7 @@ def _save_study_shm(job, echo, nframes, flow_deflate_level=None):
         nparr = _shm_get(nparr, blocks)
         mask_dict = {k: _shm_get(v, blocks) for k, v in mask_dict.items()}
         echo = _shm_get(echo, blocks)
-        save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, *rest, echo=echo, nframes=nframes, flow_deflate_level=flow_deflate_level)
+        save_optical_flow_to_hdf5(save_path, flow_arr, nparr, mask_dict, *rest, echo=echo, nframes=nframes)
         del flow_arr, nparr, mask_dict, echo
     finally:
         _shm_release(blocks, unlink=False)
@@ -448,11 +448,59 @@ def _prepare_study(reader, path, mode, flipLR, config, want_echo):
     return nparr, md, pid, hr, masks_ahead, echo
 
 
+def _spawn_unsafe_reason(reader):
+    """Why worker PROCESSES cannot serve this call, or None.  They are started with the spawn method (a process must never be forked
+    from one that has initialised the GPU): the child re-imports the caller's `__main__` module from its file and unpickles `reader`.
+    So (1) `reader` must pickle -- a lambda or a closure does not -- and (2) if `__main__` is a script, the call must come from under
+    its `if __name__ == "__main__":` guard; otherwise the child would run the script's top level again and die in its bootstrap
+    (every study would then come back as BrokenProcessPool).  Both are checked here, before a pool exists."""
+    import pickle
+    import sys
+    try:
+        pickle.dumps(reader)
+    except Exception as e:
+        return f"reader={reader!r} does not pickle ({type(e).__name__}: {e})"
+    import __main__
+    main_file = getattr(__main__, "__file__", None)
+    if not main_file or not os.path.exists(main_file):
+        return None                                           # python -c / interactive: spawn has no __main__ file to re-run
+    fr = sys._getframe()
+    while fr is not None and not (fr.f_code.co_name == "<module>" and fr.f_globals.get("__name__") == "__main__"):
+        fr = fr.f_back
+    if fr is None:
+        return None                                           # not called from __main__'s module-level code (a thread, an importing tool)
+    try:
+        import ast
+        with open(main_file) as fh:
+            tree = ast.parse(fh.read())
+    except (OSError, SyntaxError, ValueError):
+        return f"cannot read {main_file} to see whether the call is under its __main__ guard"
+
+    def is_guard(test):
+        if not (isinstance(test, ast.Compare) and len(test.ops) == 1 and isinstance(test.ops[0], ast.Eq)):
+            return False
+        sides = [test.left, test.comparators[0]]
+        return any(isinstance(x, ast.Name) and x.id == "__name__" for x in sides) and \
+            any(isinstance(x, ast.Constant) and x.value == "__main__" for x in sides)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.If) and is_guard(node.test) and node.body and node.body[0].lineno <= fr.f_lineno <= node.body[-1].end_lineno:
+            return None
+    return (f"the call comes from module-level code of the script {os.path.basename(main_file)} (line {fr.f_lineno}) outside an "
+            "`if __name__ == '__main__':` block, which a spawned worker would run again")
+
+
+def _is_pool_failure(e):
+    """An exception that condemns the worker pools, not the study: a worker died or an argument / result would not pickle."""
+    import pickle
+    from concurrent.futures.process import BrokenProcessPool
+    return isinstance(e, (BrokenProcessPool, pickle.PicklingError)) or (isinstance(e, (AttributeError, TypeError)) and "pickle" in str(e).lower())
+
+
 def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, chunk_index=0, mode="RVIO_2class", bkgd_comp="none",
                    flipLR=False, verbose=True, recalculate=False, no_saliency=True, OF_algo="TVL1", save_mask_subset=None,
                    include_waveforms=False, waveform_folder=None, pixel_spacing=None, frame_rate=None, process_subset=False,
                    file_subset_list=(), *, rank=0, world=1, extensions=("dcm",), reader=read_study, flow_model=None, config=None,
-                   device_id=0, workers="auto", n_readers=None, n_writers=None, flow_deflate_level=None):
+                   device_id=0, workers="auto", n_readers=None, n_writers=None):
     """Drop-in for the reference's process_folder (:243-290), same positional signature and the same rules:
       * the folder listing is cut into `nchunks` slices of len // nchunks files, this call takes slice `chunk_index`
         (the remainder files are dropped, as the reference does -- SURVEY.md Appendix C.8);
@@ -468,9 +516,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     writer stages in `n_readers` + `n_writers` worker PROCESSES (spawned here, before this call's first GPU call; the mask stage and
     the deflate both hold the interpreter lock, which is why threads bought 3 %), "thread" in one thread each, "auto" takes
     processes when this call creates the flow model itself (no `flow_model`, no `segmentor_model`: nothing in the caller's hands has
-    initialised the GPU yet as far as this function can tell) and more than one study is to do.  `flow_deflate_level` (None = 9 = the
-    reference's bytes): zlib effort for the `flow` / `echo` chunks, see hdf5_out.save_optical_flow_to_hdf5.  Returns the list of
-    (filename, error string)."""
+    initialised the GPU yet as far as this function can tell) and more than one study is to do.  Returns the list of (filename, error string)."""
     os.makedirs(save_folder, exist_ok=True)
     file_list = sorted(os.listdir(dcm_folder))                      # os.listdir order is arbitrary; sorted = same slices on every rank
     errors = []
@@ -494,13 +540,19 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     n_readers = _default_stage_workers() if n_readers is None else n_readers
     n_writers = _default_stage_workers() if n_writers is None else n_writers
     use_proc = workers == "process" or (workers == "auto" and flow_model is None and segmentor_model is None)
-    state = {"writer": None, "reader_pool": None, "proc": False}
+    state = {"writer": None, "reader_pool": None, "proc": False, "fallback": None, "depth": 1}
     studies = {}                # save_path -> what of a study lives in shared memory until its writer is done
 
     def start_pools(n_todo):
         # worker processes only make sense for more than one study, and they must exist before the first GPU call of this function
         if shared is not None:
             state["reader_pool"], state["writer"], state["proc"] = shared.readers, shared.writers, True
+        elif use_proc and n_todo > 1 and (why := _spawn_unsafe_reason(reader)) is not None:
+            # (the :=-bound reason is logged; the walk is the same, its reader and writer stages run in one thread each)
+            logger.warning(f"process_folder: worker processes not used, threads instead: {why}")
+            state["fallback"] = why
+            state["reader_pool"] = ThreadPoolExecutor(1)
+            state["writer"] = ThreadPoolExecutor(1)
         elif use_proc and n_todo > 1:
             import multiprocessing as mp
             from concurrent.futures import ProcessPoolExecutor
@@ -533,9 +585,9 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
             masks = study.get("mask_descs") if study.get("mask_descs") is not None and mask_dict is study.get("mask_views") else mask_dict
             echo_d = study.get("echo_desc", echo)
             job = (save_path, flow16, None if echo_d is not None else nparr, masks, *rest)
-            pending.append((save_path, state["writer"].submit(_save_study_shm, job, echo_d, int(np.asarray(nparr).shape[0]), flow_deflate_level)))
+            pending.append((save_path, state["writer"].submit(_save_study_shm, job, echo_d, int(np.asarray(nparr).shape[0]))))
         else:
-            pending.append((job[0], state["writer"].submit(save_optical_flow_to_hdf5, *job, flow_deflate_level=flow_deflate_level)))
+            pending.append((job[0], state["writer"].submit(save_optical_flow_to_hdf5, *job)))
 
     def drop_study(save_path):
         study = studies.pop(save_path, None)
@@ -569,23 +621,52 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 continue
             todo.append((filename, stem, save_path))
         start_pools(len(todo))
-        depth = n_readers if state["proc"] else 1               # studies the reader stage may be ahead of the solver
+        state["depth"] = n_readers if state["proc"] else 1      # studies the reader stage may be ahead of the solver
         futs = {}
 
         def submit(k):
             if k < len(todo) and k not in futs:
                 futs[k] = state["reader_pool"].submit(_prepare_study_shm if state["proc"] else _prepare_study, reader,
                                                       os.path.join(dcm_folder, todo[k][0]), mode, flipLR, cfg_masks, state["proc"])
-        for k in range(min(depth, len(todo))):
+
+        def pools_to_threads(e, k):
+            # The worker pools are unusable (a worker died while starting, something would not pickle): the stages go on in threads,
+            # as rounds 2-3 ran them.  Studies already handed to the writer pool are reaped (and reported) as they are.
+            why = f"{type(e).__name__}: {e}"
+            logger.warning(f"process_folder: worker processes failed ({why}); the reader and writer stages continue in threads")
+            state["fallback"] = why
+            reap(block=True)
+            for kk, fut in list(futs.items()):
+                fut.cancel()
+                try:
+                    res = fut.result(timeout=0) if fut.done() and not fut.cancelled() else None
+                    if res is not None:
+                        _shm_unlink_names([res[0], res[5]] + list((res[4] or {}).values()))
+                except Exception:
+                    pass
+                del futs[kk]
+            for pool in (state["writer"], state["reader_pool"]):
+                pool.shutdown(wait=False, cancel_futures=True)
+            state["reader_pool"], state["writer"], state["proc"], state["depth"] = ThreadPoolExecutor(1), ThreadPoolExecutor(1), False, 1
+            submit(k)
+        for k in range(min(state["depth"], len(todo))):
             submit(k)
         for k, (filename, stem, save_path) in enumerate(todo):
             if verbose:
                 logger.info(f"Processing file: {filename}...")
-            submit(k + depth)
+            submit(k)                                                 # (already there unless the pools have just been rebuilt)
+            submit(k + state["depth"])
             deferred = len(pending)
             nparr = masks_ahead = echo = None
             try:
-                nparr, md, pid, hr, masks_ahead, echo = futs.pop(k).result()
+                try:
+                    prepared = futs.pop(k).result()
+                except Exception as e:
+                    if not (state["proc"] and shared is None and _is_pool_failure(e)):
+                        raise
+                    pools_to_threads(e, k)
+                    prepared = futs.pop(k).result()
+                nparr, md, pid, hr, masks_ahead, echo = prepared
                 if state["proc"]:
                     # map what the reader stage left in shared memory; the descriptors go on to the writer stage as they are
                     study = studies[save_path] = {"blocks": [], "descs": [nparr, echo] + list((masks_ahead or {}).values())}

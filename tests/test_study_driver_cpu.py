@@ -189,20 +189,6 @@ if __name__ == "__main__":
     shm_before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
     e2 = process_folder(src, os.path.join(TMP, "prc"), None, workers="process", n_readers=2, n_writers=2, **kw)
     shm_left = sorted((set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()) - shm_before)
-    # opt-in: flow / echo chunks stored uncompressed inside valid deflate streams -- same datasets, filters, values for any reader
-    e3 = process_folder(src, os.path.join(TMP, "lvl0"), None, workers="process", n_readers=2, n_writers=2, flow_deflate_level=0, **kw)
-    e4 = process_folder(src, os.path.join(TMP, "lvl0t"), None, workers="thread", flow_deflate_level=0, **kw)
-    same0 = [e[0] for e in e3] == ["s8.npz", "s9.npz"] and [e[0] for e in e4] == ["s8.npz", "s9.npz"]
-    bigger = True
-    for sub in ("lvl0", "lvl0t"):
-        for k in range(4):
-            with h5py.File(os.path.join(TMP, "thr", f"s{k}.hdf5"), "r") as a, h5py.File(os.path.join(TMP, sub, f"s{k}.hdf5"), "r") as b:
-                same0 &= sorted(a.keys()) == sorted(b.keys())
-                for key in a.keys():
-                    same0 &= a[key].dtype == b[key].dtype and a[key].shape == b[key].shape and bool(np.array_equal(a[key][...], b[key][...]))
-                    same0 &= a[key].compression == b[key].compression and a[key].compression_opts == b[key].compression_opts and a[key].chunks == b[key].chunks
-                bigger &= b["flow"].id.get_storage_size() > a["flow"].id.get_storage_size()
-                bigger &= b["otsu"].id.get_storage_size() == a["otsu"].id.get_storage_size()
     from tee_optical_flow_amd import pipeline
     same = True
     for k in range(4):
@@ -215,7 +201,7 @@ if __name__ == "__main__":
                 w = b["flow"].attrs[n]
                 same &= bool(np.array_equal(np.asarray(v), np.asarray(w))) and type(v) is type(w)
     print(json.dumps({"e1": e1, "e2": e2, "same": bool(same), "files": sorted(os.listdir(os.path.join(TMP, "prc"))),
-                      "shm_left": shm_left, "shm": pipeline._shm_stats, "same0": bool(same0), "bigger": bool(bigger)}, default=str))
+                      "shm_left": shm_left, "shm": pipeline._shm_stats}, default=str))
 """
 
 
@@ -239,5 +225,89 @@ def test_process_folder_worker_processes_write_the_same_files(tmp_path):
     assert "injected" in g["e2"][0][1]
     assert g["shm_left"] == [], "shared-memory blocks left behind"
     # per study: frames + otsu mask + echo mapped, float16 flow created; the study whose solve fails maps its three and creates none
-    assert g["shm"]["mapped"] == 2 * 5 * 3 and g["shm"]["created"] == 2 * 4      # (the walk runs twice in worker processes: level 9 and level 0)
-    assert g["same0"] is True and g["bigger"] is True                              # flow_deflate_level=0: same content, only the flow / echo chunks grow
+    assert g["shm"]["mapped"] == 5 * 3 and g["shm"]["created"] == 4
+
+
+UNSAFE_DRIVER = r"""
+import sys, json, os, logging, numpy as np
+sys.path.insert(0, ROOT)
+from tee_optical_flow_amd import pipeline
+from tee_optical_flow_amd.pipeline import process_folder, read_study
+from tee_optical_flow_amd.synth import speckle_sequence
+
+class FakeModel:                        # cv2-protocol stand-in, tests only
+    def calc_batch(self, frames, scale=1.0):
+        d = (frames[1:].astype(np.float32) - frames[:-1].astype(np.float32)) / 64
+        return np.stack([d, -0.5 * d], -1) * np.float32(scale)
+    def close(self): pass
+
+def dying_reader(path):                 # picklable, but kills every worker PROCESS that runs it; in a thread of the caller it reads
+    import multiprocessing
+    if multiprocessing.parent_process() is not None:
+        os._exit(3)
+    return read_study(path)
+
+warnings = []
+class Grab(logging.Handler):
+    def emit(self, rec):
+        if rec.levelno >= logging.WARNING: warnings.append(rec.getMessage())
+pipeline.logger.addHandler(Grab())
+
+def walk(tag, reader):
+    src, dst = os.path.join(TMP, "in"), os.path.join(TMP, tag)
+    if not os.path.isdir(src):
+        os.makedirs(src)
+        for k in range(3):
+            g = speckle_sequence(300 + k, 4, 40, 48)
+            np.savez(os.path.join(src, f"s{k}.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.05, frame_rate=40.0)
+    del warnings[:]
+    errs = process_folder(src, dst, None, nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), flow_model=FakeModel(),
+                          workers="process", n_readers=2, n_writers=2, reader=reader)
+    return {"errors": errs, "files": sorted(os.listdir(dst)), "warnings": list(warnings)}
+
+MODE = sys.argv[1]
+if MODE == "unguarded":
+    # module-level call, no __main__ guard, a lambda reader: the documented hook used the careless way
+    print(json.dumps(walk("out_u", lambda p: read_study(p))))
+if __name__ == "__main__":
+    if MODE == "lambda":
+        print(json.dumps(walk("out_l", lambda p: read_study(p))))
+    elif MODE == "dying":
+        print(json.dumps(walk("out_d", dying_reader)))
+    elif MODE == "fine":
+        print(json.dumps(walk("out_f", read_study)))
+"""
+
+
+@pytest.mark.parametrize("mode,expect", [("unguarded", "does not pickle"), ("lambda", "does not pickle"), ("dying", "worker processes failed"), ("fine", None)])
+def test_process_folder_falls_back_to_threads_when_worker_processes_cannot_serve(tmp_path, mode, expect):
+    """worker processes are spawned, so the caller's __main__ is re-imported and `reader` is pickled.  A script without a
+    __main__ guard, a lambda reader or a pool whose workers die must not cost the studies: the stages fall back to threads and say why."""
+    if not os.path.exists(PY_H5):
+        pytest.skip("no interpreter with h5py")
+    script = tmp_path / "walk.py"
+    script.write_text(UNSAFE_DRIVER.replace("ROOT", repr(ROOT)).replace("TMP", repr(str(tmp_path))))
+    r = subprocess.run([PY_H5, str(script), mode], capture_output=True, text=True, timeout=300, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = json.loads(r.stdout.strip().splitlines()[-1])
+    assert g["errors"] == [] and g["files"] == ["s0.hdf5", "s1.hdf5", "s2.hdf5"], g
+    if expect is None:
+        assert not g["warnings"], g["warnings"]
+    else:
+        assert any(expect in w for w in g["warnings"]), g["warnings"]
+
+
+def test_unguarded_script_with_a_picklable_reader_is_detected(tmp_path):
+    """The other half of the up-front check: the reader pickles, but the call sits in module-level code of a script outside its
+    `if __name__ == "__main__":` block."""
+    if not os.path.exists(PY_H5):
+        pytest.skip("no interpreter with h5py")
+    script = tmp_path / "walk2.py"
+    src = UNSAFE_DRIVER.replace("ROOT", repr(ROOT)).replace("TMP", repr(str(tmp_path)))
+    src = src.replace('print(json.dumps(walk("out_u", lambda p: read_study(p))))', 'print(json.dumps(walk("out_u", read_study)))')
+    script.write_text(src)
+    r = subprocess.run([PY_H5, str(script), "unguarded"], capture_output=True, text=True, timeout=300, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = json.loads(r.stdout.strip().splitlines()[-1])
+    assert g["errors"] == [] and g["files"] == ["s0.hdf5", "s1.hdf5", "s2.hdf5"], g
+    assert any("outside an `if __name__ == '__main__':` block" in w for w in g["warnings"]), g["warnings"]

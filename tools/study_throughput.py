@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--algo", default="TVL1")
     ap.add_argument("--readers", type=int, default=2)
     ap.add_argument("--writers", type=int, default=2)
-    ap.add_argument("--flow-deflate-level", type=int, default=None, help="zlib effort for the flow / echo chunks in every leg (default 9 = the reference's bytes; 0 = stored)")
     ap.add_argument("--stages", action="store_true", help="also print where the caller's thread spends a study in the worker-process walk")
     a = ap.parse_args()
     from tee_optical_flow_amd import pipeline as P
@@ -38,8 +37,7 @@ def main():
     # the worker processes must exist before anything in this process touches the GPU
     workers = P.StudyWorkers(a.readers, a.writers)
     model = P.make_flow_model(a.algo)
-    kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo=a.algo, flow_model=model,
-              flow_deflate_level=a.flow_deflate_level)
+    kw = dict(nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo=a.algo, flow_model=model)
     P.process_folder(src, os.path.join(tmp, "warm"), None, process_subset=True, file_subset_list=["study00.npz"], workers="thread", **kw)   # warm-up: allocations, masks code paths
     P.process_folder(src, os.path.join(tmp, "warm2"), None, process_subset=True, file_subset_list=["study00.npz", "study01.npz"], workers=workers, **kw)
     # where the caller's thread spends a study in the worker-process walk: solve (flow_for_study), hand-over to the writer (defer),
@@ -95,14 +93,14 @@ def main():
         for f in files:
             nparr, md, pid, hr = P.read_study(os.path.join(args[0], f))
             P.process_video(None, os.path.join(args[1], f[:-4] + ".hdf5"), None, verbose=False, mode="otsu", no_saliency=True, OF_algo=a.algo,
-                            nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, flow_model=model, flow_deflate_level=a.flow_deflate_level)
+                            nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, flow_model=model)
     t0 = time.perf_counter()
     serial_folder(src, os.path.join(tmp, "serial"))
     t_serial = time.perf_counter() - t0
     hdf5_out.save_optical_flow_to_hdf5 = real
     model.close()
     sz = sum(os.path.getsize(os.path.join(tmp, "overlapped", f)) for f in os.listdir(os.path.join(tmp, "overlapped"))) / a.studies / 1e6
-    print(f"{a.algo}: {a.studies} studies of {a.frames} frames {a.size}x{a.size} (errors: {errs}); flow / echo deflate level {9 if a.flow_deflate_level is None else a.flow_deflate_level}")
+    print(f"{a.algo}: {a.studies} studies of {a.frames} frames {a.size}x{a.size} (errors: {errs})")
     print(f"  {a.readers} reader + {a.writers} writer PROCESSES      : {t_proc:6.2f} s = {t_proc / a.studies * 1e3:7.1f} ms per study, {a.studies * (a.frames - 1) / t_proc:7.1f} pairs/s end to end (errors: {errs_p})")
     print(f"  reader / writer threads            : {t_overlap:6.2f} s = {t_overlap / a.studies * 1e3:7.1f} ms per study, {a.studies * (a.frames - 1) / t_overlap:7.1f} pairs/s end to end")
     print(f"  write in line (reference order)    : {t_serial:6.2f} s = {t_serial / a.studies * 1e3:7.1f} ms per study, of which HDF5 gzip-9 write {t_write[0] / a.studies * 1e3:7.1f} ms; file {sz:.1f} MB per study")
