@@ -155,9 +155,11 @@ int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float 
 /* B independent pairs (BASELINE.json config 3): I0s, I1s host uint8 [B][H][W]; flow_out float32 [B][H][W][2]. */
 int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st);
 
-/* CV_32FC1 frames: cv2's DualTVL1 accepts float32 images with values in [0,1] and multiplies them by 255 when it builds
- * level 0 (the reference itself always hands over uint8, calculate_optical_flow.py:588).  Host pointers, DualTVL1 handles
- * only (TF_ERR_UNSUPPORTED for DeepFlow); otherwise identical to tf_calc_pair / tf_calc_pairs. */
+/* CV_32FC1 frames (host pointers; otherwise identical to tf_calc_pair / tf_calc_pairs).  cv2's DualTVL1 accepts float32 images with
+ * values in [0,1] and multiplies them by 255 when it builds level 0; cv2's DeepFlow converts with `convertTo(CV_32F)` and no factor,
+ * i.e. takes float frames AS THEY ARE -- a DeepFlow handle does the same (frames in [0,1] stay in [0,1]; zeta and epsilon are not
+ * rescaled).  The reference hands over uint8 with no_saliency=True (calculate_optical_flow.py:588) and computeSaliency()'s CV_32F map
+ * with no_saliency=False (:586, :631). */
 int tf_calc_pair_f32(tf_handle* h, const float* I0, const float* I1, int H, int W, float* flow_out, tf_stats* st);
 int tf_calc_pairs_f32(tf_handle* h, const float* I0s, const float* I1s, int B, int H, int W, float* flow_out, tf_stats* st);
 
@@ -187,14 +189,22 @@ int tf_condition_frames(tf_handle* h, const uint8_t* rgb, int N, int H, int W, u
 int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, tf_stats* st);
 
 /* The reference's other preprocessing branch, no_saliency=False (calculate_optical_flow.py:559-560
- * `cv2.saliency.StaticSaliencyFineGrained_create()`, :586 `saliency_obj.computeSaliency(nparr[i])`): the uint8 saliency map of
- * every frame takes the place of the conditioned gray frame as the solver's input.  frames: host uint8 [N][H][W][channels],
- * channels 3 (handed to OpenCV's BGR2GRAY in the order given, as the reference does with its RGB frames) or 1;
- * saliency_out: host uint8 [N][H][W].  tf_calc_seq_saliency = maps + tf_calc_seq without the maps returning to the host
- * (flow_out: [N-1][H][W][2]).  Restated from opencv-contrib's saliency module; nothing pins it (oracle/saliency_oracle.c). */
+ * `cv2.saliency.StaticSaliencyFineGrained_create()`, :586 `saliency_obj.computeSaliency(nparr[i])`): the saliency map of every frame
+ * takes the place of the conditioned gray frame as the solver's input.  frames: host uint8 [N][H][W][channels], channels 3 (handed to
+ * OpenCV's BGR2GRAY in the order given, as the reference does with its RGB frames) or 1.
+ *   tf_saliency_frames      -> uint8 [N][H][W]: the algorithm's 8-bit map (what opencv-contrib 3.x returned)
+ *   tf_saliency_frames_f32  -> float32 [N][H][W] = that map * (1/255), values in [0,1]: what computeSaliency() returns in
+ *                              opencv-contrib 4.x (`dst.convertTo(saliencyMap, CV_32F, 1.0f/255.0f)`), i.e. what the reference's
+ *                              OF_model.calc receives under its `opencv-contrib-python>=4.5.0` (requirements.txt:7)
+ * tf_calc_seq_saliency / _f32 = maps + tf_calc_seq without the maps returning to the host (flow_out: [N-1][H][W][2]); the _f32 form hands
+ * the solver CV_32F frames (DualTVL1 multiplies them by 255 in float, DeepFlow takes them as they are -- see tf_calc_pair_f32) and is
+ * the Python layer's default.  Restated from opencv-contrib's saliency module; nothing pins it (oracle/saliency_oracle.c). */
 int tf_saliency_frames(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, uint8_t* saliency_out);
+int tf_saliency_frames_f32(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float* saliency_out);
 int tf_calc_seq_saliency(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float scale, float* flow_out,
                          tf_stats* st);
+int tf_calc_seq_saliency_f32(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float scale, float* flow_out,
+                             tf_stats* st);
 
 /* ---- radial / longitudinal projection + per-frame statistics of the reference's analysis step
  *      (optical_flow/analysis.py:89-212: calculate_comp_magnitude, calc_bidirectional_hist), float64, on the device.

@@ -312,22 +312,20 @@ ORC_API int dfo_pyramid_sizes(const dfo_params* P, int W, int H, int* ws, int* h
     return n;
 }
 
-/* OpticalFlowDeepFlow::calc.  I0/I1 uint8 [H][W]; flow float32 [H][W][2].  Returns the number of pyramid levels. */
-ORC_API int dfo_deepflow_calc(const dfo_params* P, const uint8_t* I0u8, const uint8_t* I1u8, int H, int W, float* flow)
+/* OpticalFlowDeepFlow::calc on frames already converted to CV_32F (`convertTo(CV_32F)` without a factor: uint8 frames keep their 0..255
+ * values, float frames are taken as they are -- a saliency map in [0,1] stays in [0,1], with zeta and epsilon unchanged).
+ * flow float32 [H][W][2].  Returns the number of pyramid levels. */
+static int deepflow_core(const dfo_params* P, const float* f0, const float* f1, int H, int W, float* flow)
 {
-    if (!P || !I0u8 || !I1u8 || !flow || H < 1 || W < 1) return -1;
     enum { CAP = 256 };
     int ws[CAP], hs[CAP];
     const int L = dfo_pyramid_sizes(P, W, H, ws, hs, CAP);
     float** p0 = (float**)calloc((size_t)L, sizeof(float*));
     float** p1 = (float**)calloc((size_t)L, sizeof(float*));
     const size_t n0 = (size_t)W * H;
-    float* t = (float*)malloc(n0 * 4);
     p0[0] = (float*)malloc(n0 * 4); p1[0] = (float*)malloc(n0 * 4);
-    for (size_t i = 0; i < n0; ++i) t[i] = (float)I0u8[i];
-    dfo_gauss_blur3(t, W, H, P->sigma, p0[0]);
-    for (size_t i = 0; i < n0; ++i) t[i] = (float)I1u8[i];
-    dfo_gauss_blur3(t, W, H, P->sigma, p1[0]);
+    dfo_gauss_blur3(f0, W, H, P->sigma, p0[0]);
+    dfo_gauss_blur3(f1, W, H, P->sigma, p1[0]);
     for (int l = 1; l < L; ++l) {
         p0[l] = (float*)malloc((size_t)ws[l] * hs[l] * 4); p1[l] = (float*)malloc((size_t)ws[l] * hs[l] * 4);
         dfo_resize_linear(p0[l - 1], ws[l - 1], hs[l - 1], p0[l], ws[l], hs[l]);
@@ -349,6 +347,25 @@ ORC_API int dfo_deepflow_calc(const dfo_params* P, const uint8_t* I0u8, const ui
     }
     for (size_t i = 0; i < n0; ++i) { flow[2 * i] = u[i]; flow[2 * i + 1] = v[i]; }
     for (int l = 0; l < L; ++l) { free(p0[l]); free(p1[l]); }
-    free(p0); free(p1); free(t); free(u); free(v); free(u2); free(v2);
+    free(p0); free(p1); free(u); free(v); free(u2); free(v2);
     return L;
+}
+
+/* I0/I1 uint8 [H][W] (what the reference hands over with no_saliency=True, calculate_optical_flow.py:588, 631) */
+ORC_API int dfo_deepflow_calc(const dfo_params* P, const uint8_t* I0u8, const uint8_t* I1u8, int H, int W, float* flow)
+{
+    if (!P || !I0u8 || !I1u8 || !flow || H < 1 || W < 1) return -1;
+    const size_t n0 = (size_t)W * H;
+    float* a = (float*)malloc(n0 * 4); float* b = (float*)malloc(n0 * 4);
+    for (size_t i = 0; i < n0; ++i) { a[i] = (float)I0u8[i]; b[i] = (float)I1u8[i]; }
+    const int L = deepflow_core(P, a, b, H, W, flow);
+    free(a); free(b);
+    return L;
+}
+
+/* I0/I1 float32 [H][W], used as they are (what reaches OF_model.calc when the frames are computeSaliency()'s CV_32F maps, :586, :631) */
+ORC_API int dfo_deepflow_calc_f32(const dfo_params* P, const float* I0, const float* I1, int H, int W, float* flow)
+{
+    if (!P || !I0 || !I1 || !flow || H < 1 || W < 1) return -1;
+    return deepflow_core(P, I0, I1, H, W, flow);
 }

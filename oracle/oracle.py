@@ -259,6 +259,8 @@ def dlib():
         L.dfo_pyramid_sizes.argtypes = [C.POINTER(DfoParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.dfo_pyramid_sizes.restype = C.c_int
         L.dfo_deepflow_calc.argtypes = [C.POINTER(DfoParams), u8p, u8p, C.c_int, C.c_int, fp]
+        L.dfo_deepflow_calc_f32.argtypes = [C.POINTER(DfoParams), fp, fp, C.c_int, C.c_int, fp]
+        L.dfo_deepflow_calc_f32.restype = C.c_int
         L.dfo_deepflow_calc.restype = C.c_int
         lib()  # sets the OpenMP team size once for the process (shared libgomp)
         _dlib = L
@@ -315,12 +317,15 @@ def deepflow_variational_refine(I0, I1, u, v, alpha=4.0, delta=0.5 / 3, gamma=5.
 
 
 def deepflow_calc(I0, I1, params=None, return_levels=False):
-    I0 = np.ascontiguousarray(I0, dtype=np.uint8)
-    I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+    """uint8 frames, or float32 frames taken as they are (cv2: convertTo(CV_32F) without a factor)."""
+    f32 = np.asarray(I0).dtype == np.float32
+    I0 = np.ascontiguousarray(I0, dtype=np.float32 if f32 else np.uint8)
+    I1 = np.ascontiguousarray(I1, dtype=np.float32 if f32 else np.uint8)
     p = params if params is not None else deepflow_default_params()
     h, w = I0.shape
     flow = np.empty((h, w, 2), np.float32)
-    n = dlib().dfo_deepflow_calc(C.byref(p), I0, I1, h, w, flow.reshape(-1))
+    fn = dlib().dfo_deepflow_calc_f32 if f32 else dlib().dfo_deepflow_calc
+    n = fn(C.byref(p), I0.reshape(-1) if f32 else I0, I1.reshape(-1) if f32 else I1, h, w, flow.reshape(-1))
     if n <= 0:
         raise RuntimeError(f"dfo_deepflow_calc failed rc={n}")
     return (flow, n) if return_levels else flow
@@ -386,6 +391,8 @@ def slib():
         fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.orc_saliency_fine_grained.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_saliency_fine_grained.restype = C.c_int
+        L.orc_saliency_fine_grained_f32.argtypes = [u8p, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_saliency_fine_grained_f32.restype = C.c_int
         L.orc_sal_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_sal_blur3.argtypes = [u8p, C.c_int, C.c_int, u8p]
         L.orc_sal_integral.argtypes = [u8p, C.c_int, C.c_int, fp]
@@ -395,13 +402,16 @@ def slib():
     return _slib
 
 
-def saliency_fine_grained(img):
-    """uint8 [H,W,3] or [H,W] -> uint8 [H,W], what computeSaliency() of StaticSaliencyFineGrained returns as its map."""
+def saliency_fine_grained(img, dtype=np.uint8):
+    """uint8 [H,W,3] or [H,W] -> the map of StaticSaliencyFineGrained: uint8 [H,W] (the algorithm's 8-bit map) or, dtype=np.float32,
+    what computeSaliency() returns in opencv-contrib 4.x: that map * (1/255) as float32 in [0,1]."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     ch = 1 if img.ndim == 2 else img.shape[2]
     H, W = img.shape[:2]
-    out = np.empty((H, W), np.uint8)
-    if slib().orc_saliency_fine_grained(img, H, W, ch, out) != 0:
+    f32 = np.dtype(dtype) == np.float32
+    out = np.empty((H, W), np.float32 if f32 else np.uint8)
+    fn = slib().orc_saliency_fine_grained_f32 if f32 else slib().orc_saliency_fine_grained
+    if fn(img, H, W, ch, out.reshape(-1) if f32 else out) != 0:
         raise ValueError(f"saliency oracle rejected an image of shape {img.shape}")
     return out
 

@@ -1,6 +1,10 @@
 /* saliency_oracle.c -- CPU restatement of cv2.saliency.StaticSaliencyFineGrained.computeSaliency(), the preprocessing the
  * reference applies to every frame when no_saliency=False (/root/reference/optical_flow/calculate_optical_flow.py:559-560
- * create, :586 computeSaliency; the uint8 map then takes the place of img2uint8(rgb2gray(frame)) as the solver's input).
+ * create, :586 computeSaliency; the map then takes the place of img2uint8(rgb2gray(frame)) as the solver's input).
+ * OUTPUT TYPE: orc_saliency_fine_grained() is the 8-bit map the algorithm produces; orc_saliency_fine_grained_f32() (end of file) is
+ * what computeSaliency() returns in opencv-contrib 4.x -- that map as CV_32F in [0,1] -- and is the DEFAULT hand-over of the
+ * product path (DenseFlow.calc_study_saliency(map_dtype="f32")): DualTVL1 then multiplies by 255 in float (close to, not equal to,
+ * the integers), DeepFlow takes [0,1] frames unscaled.  The 8-bit hand-over stays selectable (map_dtype="u8").
  *
  * TEST INFRASTRUCTURE ONLY: tests/ compare the HIP kernels (teeflow_saliency.hip.h) against this file; the product never
  * links or loads it.
@@ -136,5 +140,22 @@ ORC_API int orc_saliency_fine_grained(const uint8_t* src, int H, int W, int chan
         rc = 0;
     }
     free(gray); free(tmp); free(I); free(mon); free(moff); free(ion); free(ioff);
+    return rc;
+}
+
+/* What computeSaliency() hands back in opencv-contrib 4.x: computeSaliencyImpl ends with
+ *     dst.convertTo(saliencyMap, CV_32F, 1.0f / 255.0f);      // values are in range [0; 1]
+ * i.e. the map above times (1/255) in float, one rounding per pixel (cvtScale 8u -> 32f: (float)src * (float)alpha + 0).
+ * [UPSTREAM-FROM-MEMORY like the rest of this file: the 3.x module returned the 8-bit map itself, which is why both forms exist;
+ * the reference demands opencv-contrib >= 4.5.0 (requirements.txt:7), so THIS is the map its OF_model.calc receives (:586, :631).] */
+ORC_API int orc_saliency_fine_grained_f32(const uint8_t* src, int H, int W, int channels, float* out)
+{
+    if (!out || H < 1 || W < 1) return -1;
+    const size_t n = (size_t)H * W;
+    uint8_t* m = (uint8_t*)malloc(n);
+    if (!m) return -1;
+    const int rc = orc_saliency_fine_grained(src, H, W, channels, m);
+    if (rc == 0) for (size_t i = 0; i < n; ++i) out[i] = (float)m[i] * (1.0f / 255.0f);
+    free(m);
     return rc;
 }

@@ -162,6 +162,10 @@ struct tf_handle : TfKnobs {
     float* dtmp = nullptr;                                          // unblurred level-0 frames
     float* dplanes = nullptr;                                       // 21 state planes x cap pairs
     DfBufs df = {};
+    // ---- frame preprocessing (conditioning, saliency): grow-only work buffers, freed with the handle ----
+    struct GrowBuf { void* p = nullptr; size_t cap = 0; };
+    enum { PRE_SRC, PRE_G0, PRE_G1, PRE_ION, PRE_IOFF, PRE_P, PRE_I, PRE_MON, PRE_MOFF, PRE_MX, PRE_OUT, PRE_COUNT };
+    GrowBuf pre[PRE_COUNT];
     // ---- analysis session (row f1) ----
     double* an_rad = nullptr; double* an_lon = nullptr; int anN = 0, anH = 0, anW = 0;
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
@@ -213,7 +217,7 @@ struct tf_handle : TfKnobs {
 // parts and joined them; bench.py reached the same overlap with three engines driven by Python threads (EnginePool).
 struct QJob {
     int mode = 0; const uint8_t* in0 = nullptr; const uint8_t* in1 = nullptr; int n_pairs = 0, H = 0, W = 0; float scale = 1.f;
-    float* out = nullptr; bool device = false; int src_f32 = 0;
+    float* out = nullptr; int device = 0; int src_f32 = 0;      // device: W_* bits
     tf_params P; tf_deepflow_params DP; TfKnobs knobs;      // the engine's settings when the job was queued
     int split_lanes = 1;                                    // lanes each unit is split over inside its queue lane (calc_split)
     int unit = 0, n_units = 0, next = 0, done = 0, fail_unit = -1;
@@ -777,7 +781,7 @@ int solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int off0,
     const tf_params& P = h->P;
     hipStream_t s = h->stream;
     const Geom g0 = h->lv[0];
-    if (h->src_f32) hipLaunchKernelGGL(k_f32_to_level0, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, (const float*)dframes, h->pyr[0], g0);
+    if (h->src_f32) hipLaunchKernelGGL(k_f32_to_level0, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, (const float*)dframes, h->pyr[0], g0, 1);
     else hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->pyr[0], g0);
     for (int l = 1; l < h->nlev; ++l) {
         const double sc = 1.0 / P.scale_step;   // resize(src, Size(), fx, fy): scale = 1/fx
@@ -1127,7 +1131,9 @@ int df_solve_resident(tf_handle* h, const uint8_t* dframes, int F, int B, int of
     const Geom g0 = h->dlv[0];
     float k0, k1;
     df_gauss3(h->DP.sigma, &k0, &k1);
-    hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->dtmp, g0);
+    // convertTo(CV_32F) without a factor: uint8 frames keep 0..255, float frames (a saliency map in [0,1]) are taken as they are
+    if (h->src_f32) hipLaunchKernelGGL(k_f32_to_level0, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, (const float*)dframes, h->dtmp, g0, 0);
+    else hipLaunchKernelGGL(k_u8_to_f32, dim3((g0.w + 255) / 256, g0.h, F), dim3(256), 0, s, dframes, h->dtmp, g0);
     hipLaunchKernelGGL(k_df_blur, grid64x4(g0, F), dim3(256), 0, s, h->dtmp, h->dpyr_base + h->dpyr_off[0], g0, k0, k1);
     for (int l = 1; l < h->dnlev; ++l) {
         const Geom gs = h->dlv[l - 1], gd = h->dlv[l];
@@ -1166,10 +1172,12 @@ double df_account_bytes(const tf_handle* h)
 }
 
 enum Mode { MODE_PAIRS, MODE_SEQ };
+// where a call's buffers live: bit 0 = the frames are device memory, bit 1 = the flow destination is
+enum { W_HOST = 0, W_IN_DEV = 1, W_OUT_DEV = 2, W_DEV = 3 };
 
 // common driver: device==true -> in/out pointers are device memory
 int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
-                float* flow_out, bool device, tf_stats* st)
+                float* flow_out, int device, tf_stats* st)
 {
     if (!h) return TF_ERR_INVALID_ARG;
     if (!in0 || (mode == MODE_PAIRS && !in1) || !flow_out) return fail(h, TF_ERR_INVALID_ARG, "null image/flow pointer");
@@ -1183,7 +1191,6 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     rc = deep ? df_ensure_alloc(h, H, W, n_pairs) : ensure_alloc(h, H, W, n_pairs);
     if (rc) return rc;
     if (deep) h->cap = h->dcap;
-    if (deep && h->src_f32) return fail(h, TF_ERR_UNSUPPORTED, "float32 frames are supported by the DualTVL1 engine only");
     const size_t fpx = (size_t)H * W * (h->src_f32 ? 4 : 1);   // BYTES per frame (the flow offsets below use npx)
     const size_t npx = (size_t)H * W;
     h->last_iters.assign(deep ? 0 : (size_t)n_pairs * h->nlev * h->P.warps * 2, 0);
@@ -1194,7 +1201,8 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
     // sub-batch is solved into one half of a double staging buffer and copied out on a second stream while the next one
     // is being solved.  Pageable destinations keep the simple in-order path.
     bool overlap = false;
-    if (!device) {
+    const bool in_dev = device & W_IN_DEV, out_dev = device & W_OUT_DEV;
+    if (!out_dev) {
         hipPointerAttribute_t pa;
         if (hipPointerGetAttributes(&pa, flow_out) == hipSuccess && pa.type == hipMemoryTypeHost) overlap = true;
         else (void)hipGetLastError();
@@ -1210,8 +1218,8 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         for (auto& e : h->cev) HIPC(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const size_t flow_half = (size_t)step * npx * 2;          // floats per staging half
-    if (!device) {
-        rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, (overlap ? 2 : 1) * flow_half * sizeof(float));
+    if (!in_dev || !out_dev) {
+        rc = ensure_staging(h, in_dev ? 0 : 2 * (size_t)h->cap * fpx, out_dev ? 0 : (overlap ? 2 : 1) * flow_half * sizeof(float));
         if (rc) return rc;
     }
     int kb = 0;
@@ -1223,20 +1231,20 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         HIPC(h, hipEventRecord(h->ev[0], h->stream));
         if (mode == MODE_SEQ) {
             F = nb + 1; off0 = 0; off1 = 1;
-            if (device) dfr = in0 + (size_t)c0 * fpx;
+            if (in_dev) dfr = in0 + (size_t)c0 * fpx;
             else { HIPC(h, hipMemcpyAsync(h->st_u8, in0 + (size_t)c0 * fpx, (size_t)F * fpx, hipMemcpyHostToDevice, h->stream)); dfr = h->st_u8; }
         } else {
             F = 2 * nb; off0 = 0; off1 = nb;
-            if (device && n_pairs <= h->cap && in1 == in0 + (size_t)n_pairs * fpx) dfr = in0;   // already [I0s|I1s] contiguous
+            if (in_dev && n_pairs <= h->cap && in1 == in0 + (size_t)n_pairs * fpx) dfr = in0;   // already [I0s|I1s] contiguous
             else {
-                if (device) { rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, 0); if (rc) return rc; }
-                const hipMemcpyKind k = device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+                if (in_dev) { rc = ensure_staging(h, 2 * (size_t)h->cap * fpx, 0); if (rc) return rc; }
+                const hipMemcpyKind k = in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
                 HIPC(h, hipMemcpyAsync(h->st_u8, in0 + (size_t)c0 * fpx, (size_t)nb * fpx, k, h->stream));
                 HIPC(h, hipMemcpyAsync(h->st_u8 + (size_t)nb * fpx, in1 + (size_t)c0 * fpx, (size_t)nb * fpx, k, h->stream));
                 dfr = h->st_u8;
             }
         }
-        dfl = device ? flow_out + (size_t)c0 * npx * 2 : h->st_flow + (overlap ? (size_t)(kb & 1) * flow_half : 0);
+        dfl = out_dev ? flow_out + (size_t)c0 * npx * 2 : h->st_flow + (overlap ? (size_t)(kb & 1) * flow_half : 0);
         if (overlap && kb >= 2) HIPC(h, hipStreamWaitEvent(h->stream, h->cev[2 + (kb & 1)], 0));   // that half's last copy-out
         HIPC(h, hipEventRecord(h->ev[1], h->stream));
         // what a repeat of this sub-batch must not count twice (an aborted co-resident attempt is void)
@@ -1252,7 +1260,7 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
             HIPC(h, hipStreamWaitEvent(h->copy_stream, h->cev[kb & 1], 0));
             HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * npx * 2, dfl, (size_t)nb * npx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
             HIPC(h, hipEventRecord(h->cev[2 + (kb & 1)], h->copy_stream));
-        } else if (!device)
+        } else if (!out_dev)
             HIPC(h, hipMemcpyAsync(flow_out + (size_t)c0 * npx * 2, h->st_flow, (size_t)nb * npx * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         if (!deep)
             HIPC(h, hipMemcpyAsync(h->last_iters.data() + (size_t)c0 * h->nlev * h->P.warps * 2, h->iters_dev,
@@ -1390,7 +1398,7 @@ void merge_stats(tf_stats* st, const tf_stats& sb)
 // Whatever went wrong, nothing of the failed call may still be in flight when the caller gets its buffers back (a D2H
 // copy into flow_out on the copy stream, kernels writing the caller's device buffer): drain every stream of the handle.
 int calc_common_guarded(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
-                        float* flow_out, bool device, tf_stats* st)
+                        float* flow_out, int device, tf_stats* st)
 {
     const int rc = calc_common(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
     if (rc != TF_OK && h) {
@@ -1402,7 +1410,7 @@ int calc_common_guarded(tf_handle* h, Mode mode, const uint8_t* in0, const uint8
 }
 
 int calc_split(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
-               float* flow_out, bool device, tf_stats* st)
+               float* flow_out, int device, tf_stats* st)
 {
     if (!h) return TF_ERR_INVALID_ARG;
     int L = h->lanes;
@@ -1570,13 +1578,12 @@ int pool_ensure(tf_handle* h)
 }
 
 // fills the job from the handle's current settings and hands it to the lanes
-int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, bool device)
+int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, int device)
 {
     const bool deep = h->P.algo == TF_ALGO_DEEPFLOW;
     int rc = deep ? df_validate(h, h->DP) : validate_params(h, h->P);
     if (rc) return rc;
     if ((long long)H * W > (1LL << 24)) return fail(h, TF_ERR_UNSUPPORTED, "images above 2^24 pixels are not supported");
-    if (deep && h->src_f32) return fail(h, TF_ERR_UNSUPPORTED, "float32 frames are supported by the DualTVL1 engine only");
     rc = pool_ensure(h);
     if (rc) return rc;
     j->mode = mode; j->in0 = in0; j->in1 = in1; j->n_pairs = n_pairs; j->H = H; j->W = W; j->scale = scale; j->out = flow_out; j->device = device;
@@ -1628,7 +1635,7 @@ int queue_finish(tf_handle* h, QJob* j, tf_stats* st)
 // lanes as they come free; the call returns when every lane has finished its last unit of it (a failed unit stops the job's
 // remaining units from starting; the units already running complete, so nothing of the call is in flight when it returns).
 int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale,
-               float* flow_out, bool device, tf_stats* st)
+               float* flow_out, int device, tf_stats* st)
 {
     if (!h) return TF_ERR_INVALID_ARG;
     const bool can_queue = !h->is_twin && !h->is_lane && queue_lane_count(h) > 0 && in0 && flow_out && (mode != MODE_PAIRS || in1) && H >= 1 && W >= 1 &&
@@ -1644,7 +1651,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
 }
 
 // tf_submit_*: the same job, not waited for.  Returns a ticket for tf_wait.
-int submit_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, bool device, int* ticket)
+int submit_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, int device, int* ticket)
 {
     if (!h || !ticket) return TF_ERR_INVALID_ARG;
     if (!in0 || (mode == MODE_PAIRS && !in1) || !flow_out) return fail(h, TF_ERR_INVALID_ARG, "null image/flow pointer");
@@ -1809,6 +1816,7 @@ TF_API void tf_destroy(tf_handle* h)
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     (void)tf_comm_destroy(h);
     for (auto& e : h->cev) if (e) (void)hipEventDestroy(e);
+    for (auto& b : h->pre) if (b.p) (void)hipFree(b.p);
     if (h->wa) (void)hipFree(h->wa);
     if (h->wcnt) (void)hipFree(h->wcnt);
     if (h->woff) (void)hipFree(h->woff);
@@ -2023,12 +2031,12 @@ TF_API int tf_set_profile(tf_handle* h, int level)
 
 TF_API int tf_calc_pair(tf_handle* h, const uint8_t* I0, const uint8_t* I1, int H, int W, float* flow_out, tf_stats* st)
 {
-    return calc_entry(h, MODE_PAIRS, I0, I1, 1, H, W, 1.0f, flow_out, false, st);
+    return calc_entry(h, MODE_PAIRS, I0, I1, 1, H, W, 1.0f, flow_out, W_HOST, st);
 }
 
 TF_API int tf_calc_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, tf_stats* st)
 {
-    return calc_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, st);
+    return calc_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, W_HOST, st);
 }
 
 // CV_32FC1 frames (values in [0,1]; cv2 multiplies them by 255 when it builds level 0)
@@ -2036,7 +2044,7 @@ TF_API int tf_calc_pairs_f32(tf_handle* h, const float* I0s, const float* I1s, i
 {
     if (!h) return TF_ERR_INVALID_ARG;
     h->src_f32 = 1;
-    const int rc = calc_entry(h, MODE_PAIRS, (const uint8_t*)I0s, (const uint8_t*)I1s, B, H, W, 1.0f, flow_out, false, st);
+    const int rc = calc_entry(h, MODE_PAIRS, (const uint8_t*)I0s, (const uint8_t*)I1s, B, H, W, 1.0f, flow_out, W_HOST, st);
     h->src_f32 = 0;
     return rc;
 }
@@ -2049,41 +2057,41 @@ TF_API int tf_calc_pair_f32(tf_handle* h, const float* I0, const float* I1, int 
 TF_API int tf_calc_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, tf_stats* st)
 {
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    return calc_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, false, st);
+    return calc_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, W_HOST, st);
 }
 
 TF_API int tf_calc_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W, float scale,
                                 float* dflow_out, tf_stats* st)
 {
-    return calc_entry(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, true, st);
+    return calc_entry(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, W_DEV, st);
 }
 
 TF_API int tf_calc_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, tf_stats* st)
 {
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    return calc_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, st);
+    return calc_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, W_DEV, st);
 }
 
 // ---- asynchronous forms: the job is queued on the handle's lanes and the call returns; tf_wait collects it ----------------------
 TF_API int tf_submit_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1s, int B, int H, int W, float scale, float* dflow_out, int* ticket)
 {
-    return submit_entry(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, true, ticket);
+    return submit_entry(h, MODE_PAIRS, dI0s, dI1s, B, H, W, scale, dflow_out, W_DEV, ticket);
 }
 TF_API int tf_submit_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, int* ticket)
 {
     if (!h) return TF_ERR_INVALID_ARG;
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    return submit_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, true, ticket);
+    return submit_entry(h, MODE_SEQ, dframes, nullptr, N - 1, H, W, scale, dflow_out, W_DEV, ticket);
 }
 TF_API int tf_submit_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, int* ticket)
 {
-    return submit_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, false, ticket);
+    return submit_entry(h, MODE_PAIRS, I0s, I1s, B, H, W, 1.0f, flow_out, W_HOST, ticket);
 }
 TF_API int tf_submit_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, int* ticket)
 {
     if (!h) return TF_ERR_INVALID_ARG;
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    return submit_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, false, ticket);
+    return submit_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, W_HOST, ticket);
 }
 TF_API int tf_wait(tf_handle* h, int ticket, tf_stats* st)
 {
@@ -2107,27 +2115,36 @@ TF_API int tf_wait(tf_handle* h, int ticket, tf_stats* st)
 }
 
 namespace {
-// rgb (host) -> conditioned gray frames in a fresh device buffer (caller frees)
+int pre_grow(tf_handle* h, int which, size_t bytes, void** out)
+{
+    tf_handle::GrowBuf& b = h->pre[which];
+    if (b.cap < bytes) {
+        if (b.p) { HIPC(h, hipStreamSynchronize(h->stream)); (void)hipFree(b.p); }
+        b.p = nullptr; b.cap = 0;
+        HIPC(h, hipMalloc(&b.p, bytes));
+        b.cap = bytes;
+    }
+    *out = b.p;
+    return TF_OK;
+}
+
+// rgb (host) -> conditioned gray frames in the handle's preprocessing buffer (valid until the handle's next preprocessing call)
 int condition_to_device(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t** dgray_out)
 {
     const size_t npx = (size_t)H * W;
     uint8_t* drgb = nullptr; uint8_t* dgray = nullptr; u64* mm = nullptr;
     HIPC(h, hipSetDevice(h->dev));
-    HIPC(h, hipMalloc(&drgb, (size_t)N * npx * 3));
-    hipError_t e = hipMalloc(&dgray, (size_t)N * npx);
-    if (e == hipSuccess) e = hipMalloc(&mm, (size_t)N * 2 * sizeof(u64));
+    int rc;
+    if ((rc = pre_grow(h, tf_handle::PRE_SRC, (size_t)N * npx * 3, (void**)&drgb)) || (rc = pre_grow(h, tf_handle::PRE_OUT, (size_t)N * npx, (void**)&dgray)) ||
+        (rc = pre_grow(h, tf_handle::PRE_MX, (size_t)N * 2 * sizeof(u64), (void**)&mm))) return rc;
     std::vector<u64> init((size_t)N * 2);
     for (int f = 0; f < N; ++f) { init[2 * f] = ~0ull; init[2 * f + 1] = 0ull; }
-    if (e == hipSuccess) e = hipMemcpyAsync(drgb, rgb, (size_t)N * npx * 3, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(mm, init.data(), init.size() * sizeof(u64), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-        const int gx = (int)((npx + 255) / 256);
-        hipLaunchKernelGGL(k_cond_minmax, dim3(gx < 512 ? gx : 512, N), dim3(256), 0, h->stream, drgb, npx, mm);
-        hipLaunchKernelGGL(k_cond_norm, dim3(gx, N), dim3(256), 0, h->stream, drgb, npx, mm, dgray);
-        e = hipStreamSynchronize(h->stream);
-    }
-    (void)hipFree(drgb); (void)hipFree(mm);
-    if (e != hipSuccess) { (void)hipFree(dgray); return fail(h, TF_ERR_HIP, "frame conditioning: %s", hipGetErrorString(e)); }
+    HIPC(h, hipMemcpyAsync(drgb, rgb, (size_t)N * npx * 3, hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipMemcpyAsync(mm, init.data(), init.size() * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    const int gx = (int)((npx + 255) / 256);
+    hipLaunchKernelGGL(k_cond_minmax, dim3(gx < 512 ? gx : 512, N), dim3(256), 0, h->stream, drgb, npx, mm);
+    hipLaunchKernelGGL(k_cond_norm, dim3(gx, N), dim3(256), 0, h->stream, drgb, npx, mm, dgray);
+    HIPC(h, hipStreamSynchronize(h->stream));            // `init` leaves scope; the solve may run on other streams (lanes)
     *dgray_out = dgray;
     return TF_OK;
 }
@@ -2139,9 +2156,7 @@ TF_API int tf_condition_frames(tf_handle* h, const uint8_t* rgb, int N, int H, i
     uint8_t* dgray = nullptr;
     int rc = condition_to_device(h, rgb, N, H, W, &dgray);
     if (rc) return rc;
-    hipError_t e = hipMemcpy(gray_out, dgray, (size_t)N * H * W, hipMemcpyDeviceToHost);
-    (void)hipFree(dgray);
-    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    HIPC(h, hipMemcpy(gray_out, dgray, (size_t)N * H * W, hipMemcpyDeviceToHost));
     return TF_OK;
 }
 
@@ -2152,101 +2167,93 @@ TF_API int tf_calc_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W
     uint8_t* dgray = nullptr;
     int rc = condition_to_device(h, rgb, N, H, W, &dgray);
     if (rc) return rc;
-    float* dflow = nullptr;
-    const size_t fbytes = (size_t)(N - 1) * H * W * 2 * sizeof(float);
-    hipError_t e = hipMalloc(&dflow, fbytes);
-    if (e != hipSuccess) { (void)hipFree(dgray); return fail(h, TF_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
-    rc = calc_entry(h, MODE_SEQ, dgray, nullptr, N - 1, H, W, scale, dflow, true, st);
-    if (!rc) {
-        e = hipMemcpy(flow_out, dflow, fbytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(dgray); (void)hipFree(dflow);
-    return rc;
+    // frames on the device, flows to the caller's host buffer: sub-batch by sub-batch through the pinned, overlapped copy-out path
+    return calc_entry(h, MODE_SEQ, dgray, nullptr, N - 1, H, W, scale, flow_out, W_IN_DEV, st);
 }
 
 namespace {
-// frames (host, uint8 [N][H][W][channels]) -> fine-grained saliency maps uint8 [N][H][W] in a fresh device buffer (caller frees).
-// Frames go through in chunks so that the work buffers (17 B per pixel) stay below ~2.3 GB whatever the study's length.
-struct SalBufs {
-    uint8_t *src = nullptr, *g0 = nullptr, *g1 = nullptr, *ion = nullptr, *ioff = nullptr;
-    int* P = nullptr; float* I = nullptr; uint16_t *mon = nullptr, *moff = nullptr; int* mx = nullptr;
-    ~SalBufs() { for (void* p : {(void*)src, (void*)g0, (void*)g1, (void*)ion, (void*)ioff, (void*)P, (void*)I, (void*)mon, (void*)moff, (void*)mx}) if (p) (void)hipFree(p); }
-};
-
-int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, uint8_t** dout)
+// frames (host, uint8 [N][H][W][channels]) -> fine-grained saliency maps [N][H][W] in the handle's preprocessing buffer: uint8, or
+// (f32) float = map * (1/255), what computeSaliency() returns in opencv-contrib 4.x.  Frames go through in chunks so that the work
+// buffers (17 B per pixel) stay below ~2.3 GB whatever the study's length; the buffers are the handle's and only ever grow.
+int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, bool f32, void** dout)
 {
     const size_t npx = (size_t)H * W, ipx = (size_t)(H + 1) * (W + 1);
     if (H > 65535 || N > 65535) return fail(h, TF_ERR_UNSUPPORTED, "saliency: at most 65535 rows and 65535 frames per call");
     size_t F = ((size_t)1 << 27) / npx;
     F = F < 1 ? 1 : (F > (size_t)N ? (size_t)N : F);
     HIPC(h, hipSetDevice(h->dev));
-    SalBufs b;
-    uint8_t* out = nullptr;
-    HIPC(h, hipMalloc(&b.src, F * npx * channels));
-    HIPC(h, hipMalloc(&b.g0, F * npx)); HIPC(h, hipMalloc(&b.g1, F * npx));
-    HIPC(h, hipMalloc(&b.ion, F * npx)); HIPC(h, hipMalloc(&b.ioff, F * npx));
-    HIPC(h, hipMalloc(&b.P, F * npx * sizeof(int))); HIPC(h, hipMalloc(&b.I, F * ipx * sizeof(float)));
-    HIPC(h, hipMalloc(&b.mon, F * npx * sizeof(uint16_t))); HIPC(h, hipMalloc(&b.moff, F * npx * sizeof(uint16_t)));
-    HIPC(h, hipMalloc(&b.mx, F * 4 * sizeof(int)));
-    HIPC(h, hipMalloc(&out, (size_t)N * npx));
-    hipError_t e = hipSuccess;
-    for (size_t f0 = 0; f0 < (size_t)N && e == hipSuccess; f0 += F) {
+    uint8_t *src, *g0, *g1, *ion, *ioff, *out; int* P; float* I; uint16_t *mon, *moff; int* mx;
+    int rc;
+    if ((rc = pre_grow(h, tf_handle::PRE_SRC, F * npx * channels, (void**)&src)) || (rc = pre_grow(h, tf_handle::PRE_G0, F * npx, (void**)&g0)) ||
+        (rc = pre_grow(h, tf_handle::PRE_G1, F * npx, (void**)&g1)) || (rc = pre_grow(h, tf_handle::PRE_ION, F * npx, (void**)&ion)) ||
+        (rc = pre_grow(h, tf_handle::PRE_IOFF, F * npx, (void**)&ioff)) || (rc = pre_grow(h, tf_handle::PRE_P, F * npx * sizeof(int), (void**)&P)) ||
+        (rc = pre_grow(h, tf_handle::PRE_I, F * ipx * sizeof(float), (void**)&I)) || (rc = pre_grow(h, tf_handle::PRE_MON, F * npx * sizeof(uint16_t), (void**)&mon)) ||
+        (rc = pre_grow(h, tf_handle::PRE_MOFF, F * npx * sizeof(uint16_t), (void**)&moff)) || (rc = pre_grow(h, tf_handle::PRE_MX, F * 4 * sizeof(int), (void**)&mx)) ||
+        (rc = pre_grow(h, tf_handle::PRE_OUT, (size_t)N * npx * (f32 ? sizeof(float) : 1), (void**)&out))) return rc;
+    for (size_t f0 = 0; f0 < (size_t)N; f0 += F) {
         const int nf = (int)((size_t)N - f0 < F ? (size_t)N - f0 : F);
         const size_t n = (size_t)nf * npx;
         const dim3 g2((W + 255) / 256, H, nf), blk(256);
-        e = hipMemcpyAsync(b.src, frames + f0 * npx * channels, n * channels, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(b.mx, 0, (size_t)nf * 4 * sizeof(int), h->stream);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(sal::k_sal_gray, dim3((unsigned)((n + 255) / 256)), blk, 0, h->stream, b.src, channels, n, b.g0);
-        hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, b.g0, b.g1, H, W);
-        hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, b.g1, b.g0, H, W);
-        hipLaunchKernelGGL(sal::k_sal_rowprefix, dim3(H, nf), dim3(64), 0, h->stream, b.g0, H, W, b.P);
-        hipLaunchKernelGGL(sal::k_sal_integral, dim3((W + 1 + 255) / 256, nf), blk, 0, h->stream, b.P, H, W, b.I);
-        hipLaunchKernelGGL(sal::k_sal_scales, g2, blk, 0, h->stream, b.g0, b.I, H, W, b.mon, b.moff, b.mx);
-        hipLaunchKernelGGL(sal::k_sal_mix_scales, g2, blk, 0, h->stream, b.mon, b.moff, H, W, b.ion, b.ioff, b.mx);
-        hipLaunchKernelGGL(sal::k_sal_mix_onoff, g2, blk, 0, h->stream, b.ion, b.ioff, H, W, b.mx, out + f0 * npx);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);     // b.src is refilled by the next chunk
+        HIPC(h, hipMemcpyAsync(src, frames + f0 * npx * channels, n * channels, hipMemcpyHostToDevice, h->stream));
+        HIPC(h, hipMemsetAsync(mx, 0, (size_t)nf * 4 * sizeof(int), h->stream));
+        hipLaunchKernelGGL(sal::k_sal_gray, dim3((unsigned)((n + 255) / 256)), blk, 0, h->stream, src, channels, n, g0);
+        hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, g0, g1, H, W);
+        hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, g1, g0, H, W);
+        hipLaunchKernelGGL(sal::k_sal_rowprefix, dim3(H, nf), dim3(64), 0, h->stream, g0, H, W, P);
+        hipLaunchKernelGGL(sal::k_sal_integral, dim3((W + 1 + 255) / 256, nf), blk, 0, h->stream, P, H, W, I);
+        hipLaunchKernelGGL(sal::k_sal_scales, g2, blk, 0, h->stream, g0, I, H, W, mon, moff, mx);
+        hipLaunchKernelGGL(sal::k_sal_mix_scales, g2, blk, 0, h->stream, mon, moff, H, W, ion, ioff, mx);
+        hipLaunchKernelGGL(sal::k_sal_mix_onoff, g2, blk, 0, h->stream, ion, ioff, H, W, mx, f32 ? nullptr : out + f0 * npx,
+                           f32 ? (float*)out + f0 * npx : nullptr);
+        HIPC(h, hipGetLastError());
+        // (stream order protects `src` against the next chunk's upload: same stream)
     }
-    if (e != hipSuccess) { (void)hipFree(out); return fail(h, TF_ERR_HIP, "saliency: %s", hipGetErrorString(e)); }
+    HIPC(h, hipStreamSynchronize(h->stream));            // the solve may run on other streams (lanes)
     *dout = out;
     return TF_OK;
+}
+
+int saliency_frames(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, bool f32, void* out)
+{
+    if (!h || !frames || !out || N < 1 || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    if (channels != 1 && channels != 3) return fail(h, TF_ERR_INVALID_ARG, "saliency: frames must have 1 or 3 channels, got %d", channels);
+    void* d = nullptr;
+    int rc = saliency_to_device(h, frames, N, H, W, channels, f32, &d);
+    if (rc) return rc;
+    HIPC(h, hipMemcpy(out, d, (size_t)N * H * W * (f32 ? sizeof(float) : 1), hipMemcpyDeviceToHost));
+    return TF_OK;
+}
+
+int calc_seq_saliency(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, bool f32, float scale, float* flow_out, tf_stats* st)
+{
+    if (!h || !frames || !flow_out || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    if (channels != 1 && channels != 3) return fail(h, TF_ERR_INVALID_ARG, "saliency: frames must have 1 or 3 channels, got %d", channels);
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    void* dsal = nullptr;
+    int rc = saliency_to_device(h, frames, N, H, W, channels, f32, &dsal);
+    if (rc) return rc;
+    h->src_f32 = f32 ? 1 : 0;                            // float maps reach the solver as CV_32F frames (DualTVL1: x 255; DeepFlow: as they are)
+    rc = calc_entry(h, MODE_SEQ, (const uint8_t*)dsal, nullptr, N - 1, H, W, scale, flow_out, W_IN_DEV, st);
+    h->src_f32 = 0;
+    return rc;
 }
 }  // namespace
 
 TF_API int tf_saliency_frames(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, uint8_t* saliency_out)
 {
-    if (!h || !frames || !saliency_out || N < 1 || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
-    if (channels != 1 && channels != 3) return fail(h, TF_ERR_INVALID_ARG, "saliency: frames must have 1 or 3 channels, got %d", channels);
-    uint8_t* d = nullptr;
-    int rc = saliency_to_device(h, frames, N, H, W, channels, &d);
-    if (rc) return rc;
-    hipError_t e = hipMemcpy(saliency_out, d, (size_t)N * H * W, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    if (e != hipSuccess) return fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
-    return TF_OK;
+    return saliency_frames(h, frames, N, H, W, channels, false, saliency_out);
 }
-
+TF_API int tf_saliency_frames_f32(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float* saliency_out)
+{
+    return saliency_frames(h, frames, N, H, W, channels, true, saliency_out);
+}
 TF_API int tf_calc_seq_saliency(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float scale, float* flow_out, tf_stats* st)
 {
-    if (!h || !frames || !flow_out || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
-    if (channels != 1 && channels != 3) return fail(h, TF_ERR_INVALID_ARG, "saliency: frames must have 1 or 3 channels, got %d", channels);
-    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
-    uint8_t* dsal = nullptr;
-    int rc = saliency_to_device(h, frames, N, H, W, channels, &dsal);
-    if (rc) return rc;
-    float* dflow = nullptr;
-    const size_t fbytes = (size_t)(N - 1) * H * W * 2 * sizeof(float);
-    hipError_t e = hipMalloc(&dflow, fbytes);
-    if (e != hipSuccess) { (void)hipFree(dsal); return fail(h, TF_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
-    rc = calc_entry(h, MODE_SEQ, dsal, nullptr, N - 1, H, W, scale, dflow, true, st);
-    if (!rc) {
-        e = hipMemcpy(flow_out, dflow, fbytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(h, TF_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(dsal); (void)hipFree(dflow);
-    return rc;
+    return calc_seq_saliency(h, frames, N, H, W, channels, false, scale, flow_out, st);
+}
+TF_API int tf_calc_seq_saliency_f32(tf_handle* h, const uint8_t* frames, int N, int H, int W, int channels, float scale, float* flow_out, tf_stats* st)
+{
+    return calc_seq_saliency(h, frames, N, H, W, channels, true, scale, flow_out, st);
 }
 
 TF_API int tf_radlong_project(tf_handle* h, const float* flow, const double* centroids, int N, int H, int W,

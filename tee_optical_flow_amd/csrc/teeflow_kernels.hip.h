@@ -69,12 +69,14 @@ __global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* __restrict__ s
     dst[(size_t)f * g.plane + (size_t)y * g.pitch + x] = (float)src[((size_t)f * g.h + y) * g.w + x];
 }
 
-// CV_32FC1 frames: cv2's DualTVL1 brings them to the 0..255 range, convertTo(CV_32F, 255.0) = one fp32 multiply per pixel
-__global__ __launch_bounds__(256) void k_f32_to_level0(const float* __restrict__ src, float* __restrict__ dst, Geom g)
+// CV_32FC1 frames.  cv2's DualTVL1 brings them to the 0..255 range, convertTo(CV_32F, 255.0) = one fp32 multiply per pixel (scale255);
+// cv2's DeepFlow takes them as they are, convertTo(CV_32F) without a factor = a copy.
+__global__ __launch_bounds__(256) void k_f32_to_level0(const float* __restrict__ src, float* __restrict__ dst, Geom g, int scale255)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
     if (x >= g.w) return;
-    dst[(size_t)f * g.plane + (size_t)y * g.pitch + x] = src[((size_t)f * g.h + y) * g.w + x] * 255.0f;
+    const float v = src[((size_t)f * g.h + y) * g.w + x];
+    dst[(size_t)f * g.plane + (size_t)y * g.pitch + x] = scale255 ? v * 255.0f : v;
 }
 
 // ---------------------------------------------------------------------------------------------

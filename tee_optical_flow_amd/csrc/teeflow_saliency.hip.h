@@ -154,13 +154,16 @@ __global__ __launch_bounds__(256) void k_sal_mix_scales(const uint16_t* __restri
 }
 
 __global__ __launch_bounds__(256) void k_sal_mix_onoff(const uint8_t* __restrict__ ion, const uint8_t* __restrict__ ioff, int H, int W,
-                                                       const int* __restrict__ mx, uint8_t* __restrict__ out)
+                                                       const int* __restrict__ mx, uint8_t* __restrict__ out, float* __restrict__ outf)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
     if (x >= W) return;
     const size_t i = ((size_t)f * H + y) * W + x;
     const int m = mx[4 * f + 2] > mx[4 * f + 3] ? mx[4 * f + 2] : mx[4 * f + 3];
-    out[i] = u8_from_f64(255. * (double)(float)((int)ion[i] + (int)ioff[i]) / (double)(float)m);
+    const uint8_t v = u8_from_f64(255. * (double)(float)((int)ion[i] + (int)ioff[i]) / (double)(float)m);
+    // outf: what computeSaliency() hands back in opencv-contrib 4.x, `dst.convertTo(saliencyMap, CV_32F, 1.0f / 255.0f)` -- values in [0, 1]
+    if (outf) outf[i] = (float)v * (1.0f / 255.0f);
+    else out[i] = v;
 }
 
 }  // namespace sal

@@ -190,7 +190,7 @@ class DenseFlow:
     # ---- cv2 protocol --------------------------------------------------------------------------
     def calc(self, I0, I1, flow=None):
         """flow = OF_model.calc(I0, I1, None): uint8 [H,W] x2 -> float32 [H,W,2] (x, y displacement).  float32 frames
-        (CV_32FC1, values in [0,1]: cv2 scales them by 255) are accepted by the DualTVL1 engine like cv2 does."""
+        (CV_32FC1) are accepted like cv2 does: DualTVL1 scales values in [0,1] by 255, DeepFlow takes them as they are."""
         I0 = _u8_image_stack(I0, "I0", 2, allow_f32=True)
         I1 = _u8_image_stack(I1, "I1", 2, allow_f32=True)
         if I0.shape != I1.shape or I0.dtype != I1.dtype:
@@ -244,9 +244,10 @@ class DenseFlow:
             out[N - 1] = out[N - 2]
         return out
 
-    def saliency_frames(self, nparr):
+    def saliency_frames(self, nparr, dtype=np.float32):
         """cv2.saliency.StaticSaliencyFineGrained_create().computeSaliency(frame)[1] for every frame, on the device (reference
-        calculate_optical_flow.py:559-560, :586): uint8 [N,H,W,3] or [N,H,W] -> uint8 [N,H,W].  Three-channel frames meet
+        calculate_optical_flow.py:559-560, :586): uint8 [N,H,W,3] or [N,H,W] -> [N,H,W].  dtype float32 (default): the CV_32F map in
+        [0,1] that opencv-contrib 4.x returns; uint8: the algorithm's 8-bit map (opencv-contrib 3.x).  Three-channel frames meet
         OpenCV's BGR2GRAY in the order given, as the reference's RGB frames do."""
         nparr = np.ascontiguousarray(nparr)
         if nparr.ndim == 3:
@@ -258,21 +259,35 @@ class DenseFlow:
             if ch not in (1, 3):
                 raise OpticalFlowCalculationError(f"nparr must be [N,H,W], [N,H,W,1] or [N,H,W,3], got {nparr.shape}")
         N, H, W = nparr.shape[:3]
-        out = np.empty((N, H, W), np.uint8)
-        _lib.check(self._L.tf_saliency_frames(self._h, nparr.ctypes.data, N, H, W, ch, out.ctypes.data), self._h, "tf_saliency_frames")
+        f32 = self._map_is_f32(dtype)
+        out = np.empty((N, H, W), np.float32 if f32 else np.uint8)
+        fn = self._L.tf_saliency_frames_f32 if f32 else self._L.tf_saliency_frames
+        _lib.check(fn(self._h, nparr.ctypes.data, N, H, W, ch, out.ctypes.data), self._h, "tf_saliency_frames")
         return out
 
-    def calc_study_saliency(self, nparr, scale=1.0):
-        """RGB study uint8 [N,H,W,3] -> float32 [N-1,H,W,2] with the saliency maps as the solver's frames (no_saliency=False)."""
+    @staticmethod
+    def _map_is_f32(dtype):
+        if dtype in ("f32", "float32") or (not isinstance(dtype, str) and np.dtype(dtype) == np.float32):
+            return True
+        if dtype in ("u8", "uint8") or (not isinstance(dtype, str) and np.dtype(dtype) == np.uint8):
+            return False
+        raise OpticalFlowCalculationError(f"saliency map dtype must be float32 ('f32') or uint8 ('u8'), got {dtype!r}")
+
+    def calc_study_saliency(self, nparr, scale=1.0, pad_last=False, map_dtype="f32"):
+        """RGB study uint8 [N,H,W,3] -> float32 [N-1,H,W,2] with the saliency maps as the solver's frames (no_saliency=False).
+        map_dtype "f32" (default): the solver receives computeSaliency()'s CV_32F maps in [0,1], as under opencv-contrib >= 4.5 -- DualTVL1
+        multiplies them by 255 in float, DeepFlow takes them as they are; "u8": the 8-bit maps.  `scale` / `pad_last` as in calc_study."""
         nparr = _u8_image_stack(nparr, "nparr", 4)
         if nparr.shape[3] not in (1, 3) or nparr.shape[0] < 2:
             raise OpticalFlowCalculationError(f"nparr must be [N>=2,H,W,3], got {nparr.shape}")
         N, H, W, ch = nparr.shape
-        out = self._out((N - 1, H, W, 2))
+        out = self._out((N if pad_last else N - 1, H, W, 2))
         st = _lib.TfStats()
-        _lib.check(self._L.tf_calc_seq_saliency(self._h, nparr.ctypes.data, N, H, W, ch, float(scale), out.ctypes.data, C.byref(st)),
-                   self._h, "tf_calc_seq_saliency")
+        fn = self._L.tf_calc_seq_saliency_f32 if self._map_is_f32(map_dtype) else self._L.tf_calc_seq_saliency
+        _lib.check(fn(self._h, nparr.ctypes.data, N, H, W, ch, float(scale), out.ctypes.data, C.byref(st)), self._h, "tf_calc_seq_saliency")
         self._finish(st)
+        if pad_last:
+            out[N - 1] = out[N - 2]
         return out
 
     def wase_compensate(self, flows, bkgd_mask, scale=1.0):
@@ -291,7 +306,8 @@ class DenseFlow:
         return flows, bg
 
     def calc_pairs(self, I0s, I1s):
-        """B independent pairs: uint8 (or, DualTVL1 only, float32 in [0,1]) [B,H,W] x2 -> float32 [B,H,W,2]."""
+        """B independent pairs: uint8 or float32 [B,H,W] x2 -> float32 [B,H,W,2] (float frames: DualTVL1 scales them by 255 like cv2, DeepFlow
+        takes them as they are like cv2)."""
         I0s = _u8_image_stack(I0s, "I0s", 3, allow_f32=True)
         I1s = _u8_image_stack(I1s, "I1s", 3, allow_f32=True)
         if I0s.shape != I1s.shape or I0s.dtype != I1s.dtype:

@@ -72,19 +72,32 @@ def _compensate(flow, mask_dict, bkgd_comp):
     return flow - background
 
 
-def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conversion_factor=1.0, nparr_rgb=None, saliency=False):
+_saliency_warned = [False]
+
+
+def flow_for_study(frames_u8, OF_model, mask_dict=None, bkgd_comp="none", conversion_factor=1.0, nparr_rgb=None, saliency=False,
+                   saliency_map="f32"):
     """Reference :584-600 for already-conditioned uint8 frames [N,H,W]: N-1 flows, last one duplicated, scaled.
     All N-1 pairs are solved by ONE batched call (tf_calc_seq); background compensation (per pair) and the unit
     scale are applied in the reference's order: (flow - background) * conversion_factor.
     `saliency=True` is the no_saliency=False branch (:559-560, :586): the frames' fine-grained saliency maps, computed on the
-    device from `nparr_rgb`, are what the solver sees."""
+    device from `nparr_rgb`, are what the solver sees -- `saliency_map` "f32" (default): as CV_32F in [0,1], what computeSaliency()
+    returns under the reference's opencv-contrib >= 4.5 (DualTVL1 then scales by 255 in float, DeepFlow takes [0,1] frames as they
+    are); "u8": the 8-bit maps (opencv-contrib 3.x).  Parity of the whole branch is UNPINNED (oracle/saliency_oracle.c)."""
     if bkgd_comp not in ("WASE", "none"):
         raise OpticalFlowCalculationError(f"bkgd_comp value must be [WASE, none], got {bkgd_comp}!")
     if saliency:
         if nparr_rgb is None or not hasattr(OF_model, "calc_study_saliency"):
             raise OpticalFlowCalculationError("no_saliency=False needs the device engine (DenseFlow.calc_study_saliency) and the "
                                               "study's frames; there is no CPU saliency path")
-        flows = OF_model.calc_study_saliency(nparr_rgb)          # saliency maps (:586) + all pairs on the device
+        if not _saliency_warned[0]:
+            _saliency_warned[0] = True
+            logger.warning("no_saliency=False: the saliency preprocessing (StaticSaliencyFineGrained, map handed over as %s) is a restatement of "
+                           "opencv-contrib that no OpenCV output pins; files written on this branch are not verified against the reference's", saliency_map)
+        if bkgd_comp == "none":
+            # unit scale in the output kernel, last flow repeated inside the pinned result buffer (as the no_saliency=True branch below)
+            return OF_model.calc_study_saliency(nparr_rgb, scale=conversion_factor, pad_last=True, map_dtype=saliency_map)
+        flows = OF_model.calc_study_saliency(nparr_rgb, map_dtype=saliency_map)          # saliency maps (:586) + all pairs on the device
     elif nparr_rgb is not None and hasattr(OF_model, "calc_study"):
         if bkgd_comp == "none" and getattr(OF_model, "device_unit_scale", False):
             # the unit scale (:600, one float32 multiply per value, the same one numpy makes) is applied by the output kernel and
@@ -117,7 +130,7 @@ def _prep_frames(nparr, flipLR):
 def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode="A4C", bkgd_comp="none", flipLR=False,
                   no_saliency=False, OF_algo="TVL1", save_mask_subset=None, include_waveforms=False, waveform_folder=None,
                   config=None, *, nparr=None, metadata=None, patient_id="", heart_rate=0, waveforms=None, flow_model=None,
-                  mask_dict=None, _defer_save=None):
+                  mask_dict=None, _defer_save=None, saliency_map="f32"):
     """Same positional signature as the reference (:478-483).  Keyword-only extras let a caller inject what the
     offline image cannot provide: `nparr` (frames instead of a DICOM), `metadata`, `mask_dict` (segmentation result),
     `flow_model`.  Returns the float32 flow array [N,H,W,2] that was written."""
@@ -163,7 +176,7 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
             if not rgb_u8:
                 raise OpticalFlowCalculationError(f"no_saliency=False needs uint8 RGB frames [N,H,W,3], got {nparr.dtype} {nparr.shape}")
             flow_arr = flow_for_study(None, model, mask_dict, bkgd_comp, conversion_factor,
-                                      nparr_rgb=np.ascontiguousarray(nparr), saliency=True)
+                                      nparr_rgb=np.ascontiguousarray(nparr), saliency=True, saliency_map=saliency_map)
         else:
             on_device = hasattr(model, "calc_study") and rgb_u8
             frames = None if on_device else condition_frames(nparr)

@@ -51,9 +51,24 @@ def test_f32_rejections():
         assert np.array_equal(eng.calc(z, z), np.zeros((32, 32, 2), np.float32))
     finally:
         eng.close()
-    deep = T.DenseFlow(algo="deepflow")
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 80, 1), (90, 130, 5), (200, 260, 20)])
+def test_deepflow_takes_float_frames_as_they_are(oracle, H, W, B):
+    """cv2's DeepFlow converts with convertTo(CV_32F) and NO factor: float frames in [0,1] stay in [0,1] (a different problem from the same
+    frames in 0..255: zeta and epsilon are fixed), float frames holding 0..255 values give the uint8 frames' flow exactly."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.synth import speckle_pairs
+    f0, f1 = _f32_pairs(list(range(30, 30 + B)), H, W)
+    I0s, I1s = speckle_pairs(list(range(30, 30 + B)), H, W)
+    eng = T.DenseFlow(algo="deepflow", max_batch=8)
     try:
-        with pytest.raises(OpticalFlowCalculationError):
-            deep.calc(f, f)
+        flows = np.array(eng.calc_pairs(f0, f1)) if B > 1 else np.array(eng.calc(f0[0], f1[0]))[None]
+        for b in sorted({0, B - 1, B // 2}):
+            assert np.array_equal(flows[b], oracle.deepflow_calc(f0[b], f1[b])), f"pair {b}"
+        as_bytes = np.array(eng.calc_pairs(I0s, I1s)) if B > 1 else np.array(eng.calc(I0s[0], I1s[0]))[None]
+        same_values = np.array(eng.calc_pairs(I0s.astype(np.float32), I1s.astype(np.float32))) if B > 1 else np.array(eng.calc(I0s[0].astype(np.float32), I1s[0].astype(np.float32)))[None]
+        assert np.array_equal(as_bytes, same_values)
+        assert not np.array_equal(flows, as_bytes) and np.isfinite(flows).all()
     finally:
-        deep.close()
+        eng.close()

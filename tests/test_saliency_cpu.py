@@ -157,11 +157,14 @@ def test_pipeline_saliency_branch_needs_the_device_engine():
     seen = {}
 
     class WithSaliency:
-        def calc_study_saliency(self, rgb):
-            seen["shape"] = rgb.shape
-            return np.zeros((rgb.shape[0] - 1,) + rgb.shape[1:3] + (2,), np.float32)
+        def calc_study_saliency(self, rgb, scale=1.0, pad_last=False, map_dtype="f32"):
+            seen.update(shape=rgb.shape, map_dtype=map_dtype, pad_last=pad_last)
+            return np.zeros((rgb.shape[0] - (0 if pad_last else 1),) + rgb.shape[1:3] + (2,), np.float32)
 
     out = process_video(None, None, None, verbose=False, mode="otsu", no_saliency=False, nparr=nparr, flow_model=WithSaliency())
     assert seen["shape"] == (3, 32, 32, 3) and out.shape == (3, 32, 32, 2)
+    assert seen["map_dtype"] == "f32" and seen["pad_last"] is True          # the default hand-over: computeSaliency()'s CV_32F map (opencv-contrib >= 4.5)
+    process_video(None, None, None, verbose=False, mode="otsu", no_saliency=False, nparr=nparr, flow_model=WithSaliency(), saliency_map="u8")
+    assert seen["map_dtype"] == "u8"
     with pytest.raises(T.OpticalFlowCalculationError, match="uint8 RGB frames"):
         process_video(None, None, None, verbose=False, mode="otsu", no_saliency=False, nparr=nparr.astype(np.float32), flow_model=WithSaliency())
