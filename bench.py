@@ -712,6 +712,30 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         torch.cuda.synchronize(dev)
         out["latency_ms_single_pair"] = (time.perf_counter() - tl) / nlat * 1e3
         lat_eng.close()
+        if algo == "TVL1":
+            # the reference's default preprocessing branch, no_saliency=False (calculate_optical_flow.py:559-560, :586): fine-grained saliency maps
+            # of a study's worth of frames, CV_32F out.  Wall time includes PCIe both ways (host frames in, host maps out); the device figure is
+            # the eight kernels' HIP-event time inside the library (tools/saliency_bench.py, profiles/r05_saliency_kernel_stats.csv)
+            from tee_optical_flow_amd.synth import speckle_sequence
+            seq = speckle_sequence(3, 65, H, W)
+            rgb = np.ascontiguousarray(np.repeat(seq[..., None], 3, axis=3))
+            sal_eng = T.DenseFlow(device_id=local_rank, max_batch=1)
+            sal_eng.saliency_frames(rgb)
+            wall, devt = [], []
+            for _ in range(5):
+                ts = time.perf_counter()
+                sal_eng.saliency_frames(rgb)
+                wall.append(time.perf_counter() - ts)
+                devt.append(sal_eng.counter("saliency_kernel_us") * 1e-6)
+            sal_eng.close()
+            bpp = 42.0             # compulsory bytes per pixel of the eight passes (tools/saliency_bench.py)
+            dsec = float(np.median(devt))
+            out["saliency"] = {"frames": 65, "height": H, "width": W, "map": "float32 in [0,1] (computeSaliency() of opencv-contrib 4.x)",
+                               "saliency_ms_per_frame_512" if H == 512 else "saliency_ms_per_frame": float(np.median(wall)) / 65 * 1e3,
+                               "frames_per_s_end_to_end": 65 / float(np.median(wall)), "device_us_per_frame": dsec / 65 * 1e6,
+                               "compulsory_bytes_per_pixel": bpp, "device_GBps_of_compulsory_bytes": 65 * H * W * bpp / dsec / 1e9 if dsec else None,
+                               "frac_of_hbm_peak": 65 * H * W * bpp / dsec / 1e9 / HBM_PEAK_GBS if dsec else None,
+                               "note": "end to end = host RGB frames in, host maps out (PCIe both ways, pageable buffers); device = the eight kernels of the study, HIP events"}
         # the same step through the host-pointer entry point (PCIe in and out included) -- reported beside, never as `value`
         eng.calc_pairs(I0s, I1s)                   # result arrays come from the engine's pinned pool: this call fills it
         tp = time.perf_counter()

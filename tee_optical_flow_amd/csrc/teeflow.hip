@@ -166,6 +166,7 @@ struct tf_handle : TfKnobs {
     struct GrowBuf { void* p = nullptr; size_t cap = 0; };
     enum { PRE_SRC, PRE_G0, PRE_G1, PRE_ION, PRE_IOFF, PRE_P, PRE_I, PRE_MON, PRE_MOFF, PRE_MX, PRE_OUT, PRE_COUNT };
     GrowBuf pre[PRE_COUNT];
+    double pre_kernel_ms = 0;    // device time of the last saliency call's kernels (HIP events on the handle's stream)
     // ---- analysis session (row f1) ----
     double* an_rad = nullptr; double* an_lon = nullptr; int anN = 0, anH = 0, anW = 0;
     int lanes = 2;               // a batch of >= 32 pairs is split over this many independent (handle, stream, host thread) lanes:
@@ -1972,6 +1973,7 @@ TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
     else if (n == "coop_disabled") { v = 0; for (auto* t : all) v |= (long long)t->coop_disabled; }
     else if (n == "coop_rearms") { v = 0; for (auto* t : all) v += t->coop_rearms; }
     else if (n == "coop_cooldown") { v = 0; for (auto* t : all) v = v > t->coop_cooldown ? v : t->coop_cooldown; }
+    else if (n == "saliency_kernel_us") v = (long long)(h->pre_kernel_ms * 1000.0);
     else if (n == "queue_jobs") v = h->q_jobs;
     else if (n == "stream_retries") { v = h->stream_retries; if (h->pool) for (auto* l : h->pool->lanes) v += l->stream_retries; }
     else if (n == "streams_serialised") { v = h->streams_serialised; if (h->pool) for (auto* l : h->pool->lanes) v |= l->streams_serialised; }
@@ -2190,11 +2192,13 @@ int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W,
         (rc = pre_grow(h, tf_handle::PRE_I, F * ipx * sizeof(float), (void**)&I)) || (rc = pre_grow(h, tf_handle::PRE_MON, F * npx * sizeof(uint16_t), (void**)&mon)) ||
         (rc = pre_grow(h, tf_handle::PRE_MOFF, F * npx * sizeof(uint16_t), (void**)&moff)) || (rc = pre_grow(h, tf_handle::PRE_MX, F * 4 * sizeof(int), (void**)&mx)) ||
         (rc = pre_grow(h, tf_handle::PRE_OUT, (size_t)N * npx * (f32 ? sizeof(float) : 1), (void**)&out))) return rc;
+    h->pre_kernel_ms = 0;
     for (size_t f0 = 0; f0 < (size_t)N; f0 += F) {
         const int nf = (int)((size_t)N - f0 < F ? (size_t)N - f0 : F);
         const size_t n = (size_t)nf * npx;
         const dim3 g2((W + 255) / 256, H, nf), blk(256);
         HIPC(h, hipMemcpyAsync(src, frames + f0 * npx * channels, n * channels, hipMemcpyHostToDevice, h->stream));
+        HIPC(h, hipEventRecord(h->ev[0], h->stream));       // the eight kernels of the chunk, without the upload
         HIPC(h, hipMemsetAsync(mx, 0, (size_t)nf * 4 * sizeof(int), h->stream));
         hipLaunchKernelGGL(sal::k_sal_gray, dim3((unsigned)((n + 255) / 256)), blk, 0, h->stream, src, channels, n, g0);
         hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, g0, g1, H, W);
@@ -2206,9 +2210,12 @@ int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W,
         hipLaunchKernelGGL(sal::k_sal_mix_onoff, g2, blk, 0, h->stream, ion, ioff, H, W, mx, f32 ? nullptr : out + f0 * npx,
                            f32 ? (float*)out + f0 * npx : nullptr);
         HIPC(h, hipGetLastError());
-        // (stream order protects `src` against the next chunk's upload: same stream)
+        HIPC(h, hipEventRecord(h->ev[1], h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));        // (one chunk holds 2^27 pixels: a study is one chunk; the event pair is read per chunk)
+        float t = 0;
+        HIPC(h, hipEventElapsedTime(&t, h->ev[0], h->ev[1]));
+        h->pre_kernel_ms += t;
     }
-    HIPC(h, hipStreamSynchronize(h->stream));            // the solve may run on other streams (lanes)
     *dout = out;
     return TF_OK;
 }

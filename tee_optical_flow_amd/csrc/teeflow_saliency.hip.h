@@ -110,7 +110,10 @@ __device__ __forceinline__ void block_max2(int a, int b, int* dst)
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) { a = sa[w] > a ? sa[w] : a; b = sb[w] > b ? sb[w] : b; }
-        atomicMax(dst, a); atomicMax(dst + 1, b);
+        // A frame's ~1000 blocks all meet on these two words: look first (the words only ever grow, so a stale look can only cause an
+        // atomic that was not needed, never miss one).  The atomics themselves were 0.5 of the two kernels' time at 512 x 512.
+        if (a > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, a);
+        if (b > __hip_atomic_load(dst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst + 1, b);
     }
 }
 

@@ -87,6 +87,36 @@ def test_deepflow_oracle_vs_opencv(oracle):
     assert worst_mean <= EPE_TOL_MEAN and worst_max <= EPE_TOL_MAX
 
 
+def test_saliency_hand_over_type_and_maps_vs_opencv(oracle):
+    """The no_saliency=False branch (calculate_optical_flow.py:559-560, :586): FIRST the type computeSaliency() hands to OF_model.calc --
+    the product's default (`saliency_map="f32"`) assumes opencv-contrib 4.x's CV_32F map in [0,1]; an 8-bit map would mean "u8" is the
+    right default -- then the maps themselves against the restatement (oracle/saliency_oracle.c), then float frames through both solvers."""
+    cv2, reason = cv2_probe()
+    if cv2 is None:
+        pytest.skip(reason)
+    if not hasattr(cv2, "saliency") or not hasattr(cv2.saliency, "StaticSaliencyFineGrained_create"):
+        pytest.skip(f"{reason} has no saliency module")
+    sal = cv2.saliency.StaticSaliencyFineGrained_create()
+    frames = [np.repeat(p[0][..., None], 3, axis=2) for p in _golden_pairs()]
+    ok, m = sal.computeSaliency(frames[0])
+    assert ok
+    print(f"{reason}: computeSaliency() returns dtype {m.dtype}, range [{float(m.min())}, {float(m.max())}]")
+    assert m.dtype == np.float32 and 0.0 <= float(m.min()) and float(m.max()) <= 1.0, \
+        "computeSaliency() does not return CV_32F in [0,1]: make saliency_map='u8' the default hand-over (pipeline.flow_for_study)"
+    for f in frames:
+        ref = sal.computeSaliency(f)[1]
+        got = oracle.saliency_fine_grained(f, np.float32)
+        assert np.array_equal(got, ref), f"saliency maps differ from OpenCV's on {np.count_nonzero(got != ref)} of {got.size} pixels"
+    # the two solvers on float frames: DualTVL1 scales by 255, DeepFlow takes them as they are
+    a, b = sal.computeSaliency(frames[0])[1], sal.computeSaliency(np.repeat(_golden_pairs()[0][1][..., None], 3, axis=2))[1]
+    t = cv2.optflow.createOptFlow_DualTVL1(); t.setLambda(0.15)
+    e = _epe(oracle.tvl1_calc(a, b), t.calc(a, b, None))
+    assert e.mean() <= EPE_TOL_MEAN and e.max() <= EPE_TOL_MAX
+    if hasattr(cv2.optflow, "createOptFlow_DeepFlow"):
+        e = _epe(oracle.deepflow_calc(a, b), cv2.optflow.createOptFlow_DeepFlow().calc(a, b, None))
+        assert e.mean() <= EPE_TOL_MEAN and e.max() <= EPE_TOL_MAX
+
+
 @pytest.mark.gpu
 def test_hip_engine_vs_opencv(engine):
     """The product itself against real OpenCV, when both a GPU and cv2 are present."""
