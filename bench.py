@@ -629,6 +629,32 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                 roof["bound_note"] = ("set from the counter-derived limiter: the launch keeps its system in registers for 25 sweeps (~35 flop per compulsory byte), "
                                       "HBM traffic is far from the roof; the hbm figures above stay for the record, roofline.valu holds the fractions of the vector-ALU roof")
         if algo == "TVL1":
+            # The regime `value` is measured in (three lanes' kernels sharing the GPU), from a stored kernel trace of THIS build's timed steps
+            # (tools/timed_regime.py): the kernel's mean duration while it shares the GPU, the kernels in flight beside it, and its
+            # share-adjusted duration -- the figures above are from launches that had the GPU to themselves.
+            tr_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_timed_regime.json")))
+            tr = None
+            for f in reversed(tr_files):
+                try:
+                    with open(f) as fh:
+                        rec = json.load(fh).get(kern)
+                except (OSError, ValueError):
+                    rec = None
+                if rec and rec.get("source_fingerprint") == kernel_source_fingerprint():
+                    tr = dict(rec, source=f"profiles/{os.path.basename(f)}")
+                    break
+            if tr is not None:
+                sad = tr["mean_share_adjusted_duration_us"] * 1e-6
+                bytes_launch = traffic if traffic is not None else comp_per_launch
+                tr["bytes_per_launch_used"] = bytes_launch
+                tr["bytes_basis"] = "measured HBM bytes per launch (PMC)" if traffic is not None else "compulsory bytes per launch (30 B per px-iteration)"
+                tr["GBps_at_mean_duration"] = bytes_launch / (tr["mean_duration_us"] * 1e-6) / 1e9
+                tr["GBps_share_adjusted"] = bytes_launch / sad / 1e9
+                tr["frac_of_peak_share_adjusted"] = bytes_launch / sad / 1e9 / HBM_PEAK_GBS
+                tr["compulsory_frac_of_peak_share_adjusted"] = comp_per_launch / sad / 1e9 / HBM_PEAK_GBS
+                roof["timed_regime"] = tr
+            else:
+                roof["timed_regime"] = {"note": "no kernel trace of this build's timed steps under profiles/ (tools/timed_regime.py); the figures above describe launches that had the GPU to themselves"}
             # algorithmic (compulsory) bytes of the kernel that is actually launched: 9 plane reads + 6 writes once per TWO iterations
             roof["algorithmic_GBps_30B"] = rate * 30.0 / 1e9 if rate else None
             roof["algorithmic_bytes_per_launch_30B"] = units_per_launch * 30.0
