@@ -113,6 +113,10 @@ struct TfKnobs {
     int strip_blocks = 2048;     // target number of strip blocks per launch (sets rows per strip)
     int lag = DEFAULT_LAG;
     int slots_override = 0;      // resident blocks the strips are sized for (0 = what the occupancy query says)
+    int lane_slots_pct = 67;     // queue lanes: per cent of the resident blocks a lane sizes its strips for.  Three lanes' launches share the GPU, so a
+                                 // lane that cuts its level into one round of ALL resident blocks pays the 3 halo + 2 RY fill rows of short strips for
+                                 // parallelism the other lanes already provide (queue form, 384 pairs per call: 100 % 2728-2745, 67 % 2769-2772,
+                                 // 50 % 2767-2769, 33 % 2706-2711 pairs/s on one box)
     int coop_test_occ16 = -1, coop_test_occ8 = -1;   // tests: pretend the occupancy query answered this
     int coop_test_mute = 0;      // tests: block 0 of every co-resident launch never raises its flag -> its neighbours give up -> the call is repeated tiled
     int profile = 0;
@@ -478,6 +482,7 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
                 f = h->slots_cache.emplace(shmem * 1024 + (size_t)threads / 64, per_cu * h->num_cus).first;
             }
             slots = f->second;
+            if (h->is_lane && h->lane_slots_pct > 0 && h->lane_slots_pct < 100) slots = slots * h->lane_slots_pct / 100;
         }
         int items = 1;
         for (int n = 1; n <= B; ++n) {
@@ -1910,6 +1915,7 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
+    else if (n == "lane_slots_pct") h->lane_slots_pct = value;
     else if (n == "tile_max_w") h->tile_max_w = value;
     else if (n == "sor_rt") h->sor_rt = value ? 1 : 0;
     else if (n == "sor_rt_shape") h->sor_rt_shape = value;
@@ -2190,7 +2196,7 @@ int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W,
         (rc = pre_grow(h, tf_handle::PRE_G1, F * npx, (void**)&g1)) || (rc = pre_grow(h, tf_handle::PRE_ION, F * npx, (void**)&ion)) ||
         (rc = pre_grow(h, tf_handle::PRE_IOFF, F * npx, (void**)&ioff)) || (rc = pre_grow(h, tf_handle::PRE_P, F * npx * sizeof(int), (void**)&P)) ||
         (rc = pre_grow(h, tf_handle::PRE_I, F * ipx * sizeof(float), (void**)&I)) || (rc = pre_grow(h, tf_handle::PRE_MON, F * npx * sizeof(uint16_t), (void**)&mon)) ||
-        (rc = pre_grow(h, tf_handle::PRE_MOFF, F * npx * sizeof(uint16_t), (void**)&moff)) || (rc = pre_grow(h, tf_handle::PRE_MX, F * 4 * sizeof(int), (void**)&mx)) ||
+        (rc = pre_grow(h, tf_handle::PRE_MOFF, F * npx * sizeof(uint16_t), (void**)&moff)) || (rc = pre_grow(h, tf_handle::PRE_MX, F * SAL_MX * sizeof(int), (void**)&mx)) ||
         (rc = pre_grow(h, tf_handle::PRE_OUT, (size_t)N * npx * (f32 ? sizeof(float) : 1), (void**)&out))) return rc;
     h->pre_kernel_ms = 0;
     for (size_t f0 = 0; f0 < (size_t)N; f0 += F) {
@@ -2199,14 +2205,15 @@ int saliency_to_device(tf_handle* h, const uint8_t* frames, int N, int H, int W,
         const dim3 g2((W + 255) / 256, H, nf), blk(256);
         HIPC(h, hipMemcpyAsync(src, frames + f0 * npx * channels, n * channels, hipMemcpyHostToDevice, h->stream));
         HIPC(h, hipEventRecord(h->ev[0], h->stream));       // the eight kernels of the chunk, without the upload
-        HIPC(h, hipMemsetAsync(mx, 0, (size_t)nf * 4 * sizeof(int), h->stream));
+        HIPC(h, hipMemsetAsync(mx, 0, (size_t)nf * SAL_MX * sizeof(int), h->stream));
         hipLaunchKernelGGL(sal::k_sal_gray, dim3((unsigned)((n + 255) / 256)), blk, 0, h->stream, src, channels, n, g0);
         hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, g0, g1, H, W);
         hipLaunchKernelGGL(sal::k_sal_blur3, g2, blk, 0, h->stream, g1, g0, H, W);
         hipLaunchKernelGGL(sal::k_sal_rowprefix, dim3(H, nf), dim3(64), 0, h->stream, g0, H, W, P);
         hipLaunchKernelGGL(sal::k_sal_integral, dim3((W + 1 + 255) / 256, nf), blk, 0, h->stream, P, H, W, I);
-        hipLaunchKernelGGL(sal::k_sal_scales, g2, blk, 0, h->stream, g0, I, H, W, mon, moff, mx);
-        hipLaunchKernelGGL(sal::k_sal_mix_scales, g2, blk, 0, h->stream, mon, moff, H, W, ion, ioff, mx);
+        const dim3 g8((W + 255) / 256, (H + SAL_ROWS - 1) / SAL_ROWS, nf);
+        hipLaunchKernelGGL(sal::k_sal_scales, g8, blk, 0, h->stream, g0, I, H, W, mon, moff, mx);
+        hipLaunchKernelGGL(sal::k_sal_mix_scales, g8, blk, 0, h->stream, mon, moff, H, W, ion, ioff, mx);
         hipLaunchKernelGGL(sal::k_sal_mix_onoff, g2, blk, 0, h->stream, ion, ioff, H, W, mx, f32 ? nullptr : out + f0 * npx,
                            f32 ? (float*)out + f0 * npx : nullptr);
         HIPC(h, hipGetLastError());

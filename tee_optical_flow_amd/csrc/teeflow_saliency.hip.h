@@ -110,50 +110,62 @@ __device__ __forceinline__ void block_max2(int a, int b, int* dst)
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) { a = sa[w] > a ? sa[w] : a; b = sb[w] > b ? sb[w] : b; }
-        // A frame's ~1000 blocks all meet on these two words: look first (the words only ever grow, so a stale look can only cause an
-        // atomic that was not needed, never miss one).  The atomics themselves were 0.5 of the two kernels' time at 512 x 512.
-        if (a > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, a);
-        if (b > __hip_atomic_load(dst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst + 1, b);
+        atomicMax(dst, a); atomicMax(dst + 1, b);
     }
 }
 
-// six scales summed: mon / moff (uint16), and the per-frame maxima of the two sums -> mx[f][0..1].  grid (ceil(W/256), H, N)
+// The per-frame maxima are atomicMax words every block of the frame meets on: SAL_ROWS rows per block (one atomic pair per 256 x 8
+// pixels instead of per 256) and one 128-byte line per frame (SAL_MX ints: frames do not share a line) -- with one row per block and
+// four ints per frame the atomics were ~0.8 of the two kernels' time at 512 x 512 (133 k of them serialised on nine cache lines).
+#define SAL_ROWS 8
+#define SAL_MX 32
+
+// six scales summed: mon / moff (uint16), and the per-frame maxima of the two sums -> mx[f][0..1].  grid (ceil(W/256), ceil(H/SAL_ROWS), N)
 __global__ __launch_bounds__(256) void k_sal_scales(const uint8_t* __restrict__ gray, const float* __restrict__ I, int H, int W,
                                                     uint16_t* __restrict__ mon, uint16_t* __restrict__ moff, int* __restrict__ mx)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    int son = 0, soff = 0;
+    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
+    int mxon = 0, mxoff = 0;
     if (x < W) {
-        const size_t i = ((size_t)f * H + y) * W + x;
         const float* If = I + (size_t)f * (H + 1) * (W + 1);
-        const int g = gray[i];
         const int nbs[6] = {12, 24, 48, 28, 56, 112};
+        const int yend = min(H, (int)(blockIdx.y + 1) * SAL_ROWS);
+        for (int y = blockIdx.y * SAL_ROWS; y < yend; ++y) {
+            const size_t i = ((size_t)f * H + y) * W + x;
+            const int g = gray[i];
+            int son = 0, soff = 0;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const float value = surround_mean(If, W + 1, H + 1, x, y, nbs[s], g);
-            const float on = (float)g - value, off = value - (float)g;
-            if (on > 0) son += u8_from_f64((double)on);
-            if (off > 0) soff += u8_from_f64((double)off);
+            for (int s = 0; s < 6; ++s) {
+                const float value = surround_mean(If, W + 1, H + 1, x, y, nbs[s], g);
+                const float on = (float)g - value, off = value - (float)g;
+                if (on > 0) son += u8_from_f64((double)on);
+                if (off > 0) soff += u8_from_f64((double)off);
+            }
+            mon[i] = (uint16_t)son; moff[i] = (uint16_t)soff;
+            mxon = son > mxon ? son : mxon; mxoff = soff > mxoff ? soff : mxoff;
         }
-        mon[i] = (uint16_t)son; moff[i] = (uint16_t)soff;
     }
-    block_max2(son, soff, mx + 4 * f);
+    block_max2(mxon, mxoff, mx + SAL_MX * f);
 }
 
-// each sum scaled to 0..255 by its maximum; maxima of the two scaled maps -> mx[f][2..3]
+// each sum scaled to 0..255 by its maximum; maxima of the two scaled maps -> mx[f][2..3].  Same grid.
 __global__ __launch_bounds__(256) void k_sal_mix_scales(const uint16_t* __restrict__ mon, const uint16_t* __restrict__ moff, int H, int W,
                                                         uint8_t* __restrict__ ion, uint8_t* __restrict__ ioff, int* __restrict__ mx)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    int a = 0, b = 0;
+    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
+    int ma = 0, mb = 0;
     if (x < W) {
-        const size_t i = ((size_t)f * H + y) * W + x;
-        const float max_on = (float)mx[4 * f], max_off = (float)mx[4 * f + 1];
-        a = u8_from_f64(255. * (double)((float)mon[i] / max_on));
-        b = u8_from_f64(255. * (double)((float)moff[i] / max_off));
-        ion[i] = (uint8_t)a; ioff[i] = (uint8_t)b;
+        const float max_on = (float)mx[SAL_MX * f], max_off = (float)mx[SAL_MX * f + 1];
+        const int yend = min(H, (int)(blockIdx.y + 1) * SAL_ROWS);
+        for (int y = blockIdx.y * SAL_ROWS; y < yend; ++y) {
+            const size_t i = ((size_t)f * H + y) * W + x;
+            const int a = u8_from_f64(255. * (double)((float)mon[i] / max_on));
+            const int b = u8_from_f64(255. * (double)((float)moff[i] / max_off));
+            ion[i] = (uint8_t)a; ioff[i] = (uint8_t)b;
+            ma = a > ma ? a : ma; mb = b > mb ? b : mb;
+        }
     }
-    block_max2(a, b, mx + 4 * f + 2);
+    block_max2(ma, mb, mx + SAL_MX * f + 2);
 }
 
 __global__ __launch_bounds__(256) void k_sal_mix_onoff(const uint8_t* __restrict__ ion, const uint8_t* __restrict__ ioff, int H, int W,
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(256) void k_sal_mix_onoff(const uint8_t* __restrict
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
     if (x >= W) return;
     const size_t i = ((size_t)f * H + y) * W + x;
-    const int m = mx[4 * f + 2] > mx[4 * f + 3] ? mx[4 * f + 2] : mx[4 * f + 3];
+    const int m = mx[SAL_MX * f + 2] > mx[SAL_MX * f + 3] ? mx[SAL_MX * f + 2] : mx[SAL_MX * f + 3];
     const uint8_t v = u8_from_f64(255. * (double)(float)((int)ion[i] + (int)ioff[i]) / (double)(float)m);
     // outf: what computeSaliency() hands back in opencv-contrib 4.x, `dst.convertTo(saliencyMap, CV_32F, 1.0f / 255.0f)` -- values in [0, 1]
     if (outf) outf[i] = (float)v * (1.0f / 255.0f);
