@@ -180,6 +180,10 @@ int tf_submit_pairs_device(tf_handle* h, const uint8_t* dI0s, const uint8_t* dI1
 int tf_submit_seq_device(tf_handle* h, const uint8_t* dframes, int N, int H, int W, float scale, float* dflow_out, int* ticket);
 int tf_submit_pairs(tf_handle* h, const uint8_t* I0s, const uint8_t* I1s, int B, int H, int W, float* flow_out, int* ticket);
 int tf_submit_seq(tf_handle* h, const uint8_t* frames, int N, int H, int W, float scale, float* flow_out, int* ticket);
+/* tf_calc_seq_rgb (below) without waiting: the frames are conditioned at once, into device memory the job owns; `rgb` may be reused as
+ * soon as the call returns, `flow_out` belongs to the job until tf_wait.  What process_folder uses to keep the next study's solve on
+ * the GPU while the previous one finishes. */
+int tf_submit_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, int* ticket);
 int tf_wait(tf_handle* h, int ticket, tf_stats* st);
 
 /* Frame conditioning of the reference's loop, `img2uint8(rgb2gray(nparr[i]))` (calculate_optical_flow.py:588,

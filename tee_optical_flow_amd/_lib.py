@@ -19,7 +19,7 @@ PARAM_KEYS = {
 EXPORTED_SYMBOLS = [
     "tf_abi_version", "tf_device_count", "tf_default_params", "tf_create", "tf_destroy", "tf_set_param",
     "tf_get_param", "tf_set_stream", "tf_set_profile", "tf_calc_pair", "tf_calc_seq", "tf_calc_pairs", "tf_calc_pair_f32", "tf_calc_pairs_f32",
-    "tf_calc_pairs_device", "tf_calc_seq_device", "tf_submit_pairs_device", "tf_submit_seq_device", "tf_submit_pairs", "tf_submit_seq", "tf_wait", "tf_condition_frames", "tf_calc_seq_rgb", "tf_saliency_frames", "tf_saliency_frames_f32", "tf_calc_seq_saliency", "tf_calc_seq_saliency_f32", "tf_radlong_project", "tf_radlong_hist", "tf_radlong_select", "tf_get_iters", "tf_last_error",
+    "tf_calc_pairs_device", "tf_calc_seq_device", "tf_submit_pairs_device", "tf_submit_seq_device", "tf_submit_pairs", "tf_submit_seq", "tf_submit_seq_rgb", "tf_wait", "tf_condition_frames", "tf_calc_seq_rgb", "tf_saliency_frames", "tf_saliency_frames_f32", "tf_calc_seq_saliency", "tf_calc_seq_saliency_f32", "tf_radlong_project", "tf_radlong_hist", "tf_radlong_select", "tf_get_iters", "tf_last_error",
     "tf_set_tuning", "tf_dbg_counter", "tf_default_deepflow_params", "tf_create_deepflow", "tf_dbg_df_refine", "tf_dbg_df_blur", "tf_dbg_launch_profile", "tf_dbg_strip_rule", "tf_wase_compensate", "tf_wase_compensate_device", "tf_host_alloc", "tf_host_free",
     "tf_dbg_pyramid", "tf_dbg_resize", "tf_dbg_warp", "tf_dbg_median", "tf_dbg_iterate",
     "tf_comm_unique_id", "tf_comm_init_rank", "tf_comm_init_all", "tf_allgather_flows", "tf_allgather_flows_all", "tf_comm_wait", "tf_comm_destroy",
@@ -110,6 +110,7 @@ def load():
         L.tf_submit_seq_device.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(i32)]
         L.tf_submit_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
         L.tf_submit_seq.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(i32)]
+        L.tf_submit_seq_rgb.argtypes = [vp, vp, i32, i32, i32, f32, vp, C.POINTER(i32)]
         L.tf_wait.argtypes = [vp, i32, C.POINTER(TfStats)]
     L.tf_condition_frames.argtypes = [vp, vp, i32, i32, i32, vp]
     if "TEEFLOW_LIB" not in os.environ or hasattr(L, "tf_saliency_frames"):     # (an older A/B build may lack the round-4 entry points)

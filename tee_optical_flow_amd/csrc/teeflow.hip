@@ -231,7 +231,9 @@ struct QJob {
     std::vector<int> iters; size_t per_pair = 0; int nlev = 0, warps = 0;
     double t0 = 0;
     std::function<void(QJob*)> on_done;                     // run once, by the lane that finishes the last unit, before `finished`
+    void* owned_dev = nullptr;                              // device memory that lives as long as the job (tf_submit_seq_rgb: the conditioned frames)
     bool finished = false;
+    ~QJob() { if (owned_dev) (void)hipFree(owned_dev); }
 };
 struct LanePool {
     std::mutex m; std::condition_variable cv_work, cv_done;
@@ -1657,13 +1659,17 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
 }
 
 // tf_submit_*: the same job, not waited for.  Returns a ticket for tf_wait.
-int submit_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, int device, int* ticket)
+int submit_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, int device, int* ticket,
+                 void* owned_dev = nullptr)
 {
+    struct Guard { void* p; ~Guard() { if (p) (void)hipFree(p); } } guard{owned_dev};
     if (!h || !ticket) return TF_ERR_INVALID_ARG;
     if (!in0 || (mode == MODE_PAIRS && !in1) || !flow_out) return fail(h, TF_ERR_INVALID_ARG, "null image/flow pointer");
     if (H < 1 || W < 1 || n_pairs < 1) return fail(h, TF_ERR_INVALID_ARG, "bad sizes: pairs=%d H=%d W=%d", n_pairs, H, W);
     if (h->is_twin || h->is_lane || h->stream != h->own_stream) return fail(h, TF_ERR_UNSUPPORTED, "tf_submit_* needs the handle's own stream");
+    guard.p = nullptr;                                       // from here on the job owns it
     QJob* j = new QJob();
+    j->owned_dev = owned_dev;                                // (freed with the job, whatever happens below)
     int rc;
     if (queue_lane_count(h) < 1) {                           // "queue_lanes" = 0: no lanes, the job is done when the call returns
         tf_stats st;
@@ -2101,6 +2107,21 @@ TF_API int tf_submit_seq(tf_handle* h, const uint8_t* frames, int N, int H, int 
     if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
     return submit_entry(h, MODE_SEQ, frames, nullptr, N - 1, H, W, scale, flow_out, W_HOST, ticket);
 }
+namespace { int condition_to_device(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t** dgray_out, uint8_t* own); }
+// tf_calc_seq_rgb without waiting: the frames are conditioned now (on the handle's stream, into a buffer the job owns), the solve is queued
+TF_API int tf_submit_seq_rgb(tf_handle* h, const uint8_t* rgb, int N, int H, int W, float scale, float* flow_out, int* ticket)
+{
+    if (!h || !rgb || !flow_out || !ticket || H < 1 || W < 1) return TF_ERR_INVALID_ARG;
+    if (N < 2) return fail(h, TF_ERR_INVALID_ARG, "a sequence needs at least 2 frames, got %d", N);
+    HIPC(h, hipSetDevice(h->dev));
+    uint8_t* own = nullptr;
+    HIPC(h, hipMalloc(&own, (size_t)N * H * W));
+    uint8_t* dgray = nullptr;
+    int rc = condition_to_device(h, rgb, N, H, W, &dgray, own);
+    if (rc) { (void)hipFree(own); return rc; }
+    return submit_entry(h, MODE_SEQ, own, nullptr, N - 1, H, W, scale, flow_out, W_IN_DEV, ticket, own);
+}
+
 TF_API int tf_wait(tf_handle* h, int ticket, tf_stats* st)
 {
     if (!h) return TF_ERR_INVALID_ARG;
@@ -2137,13 +2158,14 @@ int pre_grow(tf_handle* h, int which, size_t bytes, void** out)
 }
 
 // rgb (host) -> conditioned gray frames in the handle's preprocessing buffer (valid until the handle's next preprocessing call)
-int condition_to_device(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t** dgray_out)
+// (`own`: into that caller-owned buffer instead -- a submitted job's frames must outlive the handle's next preprocessing call)
+int condition_to_device(tf_handle* h, const uint8_t* rgb, int N, int H, int W, uint8_t** dgray_out, uint8_t* own = nullptr)
 {
     const size_t npx = (size_t)H * W;
-    uint8_t* drgb = nullptr; uint8_t* dgray = nullptr; u64* mm = nullptr;
+    uint8_t* drgb = nullptr; uint8_t* dgray = own; u64* mm = nullptr;
     HIPC(h, hipSetDevice(h->dev));
     int rc;
-    if ((rc = pre_grow(h, tf_handle::PRE_SRC, (size_t)N * npx * 3, (void**)&drgb)) || (rc = pre_grow(h, tf_handle::PRE_OUT, (size_t)N * npx, (void**)&dgray)) ||
+    if ((rc = pre_grow(h, tf_handle::PRE_SRC, (size_t)N * npx * 3, (void**)&drgb)) || (!own && (rc = pre_grow(h, tf_handle::PRE_OUT, (size_t)N * npx, (void**)&dgray))) ||
         (rc = pre_grow(h, tf_handle::PRE_MX, (size_t)N * 2 * sizeof(u64), (void**)&mm))) return rc;
     std::vector<u64> init((size_t)N * 2);
     for (int f = 0; f < N; ++f) { init[2 * f] = ~0ull; init[2 * f + 1] = 0ull; }

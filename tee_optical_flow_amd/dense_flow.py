@@ -351,6 +351,19 @@ class DenseFlow:
         self._jobs[t.value] = (out, frames)                 # the library reads `frames` and writes `out` until the wait
         return t.value
 
+    def submit_study(self, nparr, scale=1.0, pad_last=False):
+        """calc_study without waiting: RGB study uint8 [N,H,W,3] -> ticket; `wait(ticket)` returns float32 [N-1,H,W,2] (or [N,H,W,2] with
+        the last flow repeated, `pad_last`).  The frames are conditioned on the device before this returns (nparr may be reused at once)."""
+        nparr = _u8_image_stack(nparr, "nparr", 4)
+        if nparr.shape[3] != 3 or nparr.shape[0] < 2:
+            raise OpticalFlowCalculationError(f"nparr must be [N>=2,H,W,3], got {nparr.shape}")
+        N, H, W, _ = nparr.shape
+        out = self._out((N if pad_last else N - 1, H, W, 2))
+        t = C.c_int(-1)
+        _lib.check(self._L.tf_submit_seq_rgb(self._h, nparr.ctypes.data, N, H, W, float(scale), out.ctypes.data, C.byref(t)), self._h, "tf_submit_seq_rgb")
+        self._jobs[t.value] = (out, ("pad_last", N) if pad_last else None)
+        return t.value
+
     def submit_pairs(self, I0s, I1s):
         """calc_pairs without waiting: uint8 [B,H,W] x2 -> ticket; `wait(ticket)` returns float32 [B,H,W,2]."""
         I0s = _u8_image_stack(I0s, "I0s", 3)
@@ -373,7 +386,11 @@ class DenseFlow:
         st = _lib.TfStats()
         _lib.check(self._L.tf_wait(self._h, int(ticket), C.byref(st)), self._h, "tf_wait")
         self._finish(st)
-        return keep[0] if keep is not None else self.last_stats
+        if keep is None:
+            return self.last_stats
+        if len(keep) == 2 and isinstance(keep[1], tuple) and keep[1][0] == "pad_last":
+            keep[0][keep[1][1] - 1] = keep[0][keep[1][1] - 2]          # the last flow repeated (reference :599), inside the pinned buffer
+        return keep[0]
 
     def calc_seq_device(self, dframes_ptr, N, H, W, dflow_ptr, scale=1.0):
         st = _lib.TfStats()

@@ -134,6 +134,20 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
     """Same positional signature as the reference (:478-483).  Keyword-only extras let a caller inject what the
     offline image cannot provide: `nparr` (frames instead of a DICOM), `metadata`, `mask_dict` (segmentation result),
     `flow_model`.  Returns the float32 flow array [N,H,W,2] that was written."""
+    return _process_video_begin(dcm_path, save_path, segmentor_model, verbose, mode, bkgd_comp, flipLR, no_saliency, OF_algo, save_mask_subset,
+                                include_waveforms, waveform_folder, config, nparr=nparr, metadata=metadata, patient_id=patient_id,
+                                heart_rate=heart_rate, waveforms=waveforms, flow_model=flow_model, mask_dict=mask_dict, _defer_save=_defer_save,
+                                saliency_map=saliency_map)()
+
+
+def _process_video_begin(dcm_path, save_path, segmentor_model=None, verbose=True, mode="A4C", bkgd_comp="none", flipLR=False,
+                         no_saliency=False, OF_algo="TVL1", save_mask_subset=None, include_waveforms=False, waveform_folder=None,
+                         config=None, *, nparr=None, metadata=None, patient_id="", heart_rate=0, waveforms=None, flow_model=None,
+                         mask_dict=None, _defer_save=None, saliency_map="f32", _submit=False):
+    """process_video in two halves: everything up to the flow solve, then a callable that collects the flows and does the rest (waveforms,
+    hand-over to the HDF5 writer) and returns the flow array.  `_submit` (process_folder): where the engine offers it (gray-frame branch,
+    no background compensation, a model the caller holds) the solve is only SUBMITTED here -- DenseFlow.submit_study, tf_submit_seq_rgb --
+    so that the next study's solve is on the GPU while this one finishes."""
     if config is None:
         config = default_optical_flow_config()
     if mode == "otsu":
@@ -169,6 +183,7 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
             raise ConfigurationError(f"Input for mode must be [A4C, otsu, RVIO_2class], not {mode}.")
     own = flow_model is None
     model = make_flow_model(OF_algo, config) if own else flow_model
+    collect = None                                # () -> the study's flow array
     try:
         rgb_u8 = nparr.ndim == 4 and nparr.shape[3] == 3 and nparr.dtype == np.uint8
         if not no_saliency:
@@ -179,29 +194,41 @@ def process_video(dcm_path, save_path, segmentor_model=None, verbose=True, mode=
                                       nparr_rgb=np.ascontiguousarray(nparr), saliency=True, saliency_map=saliency_map)
         else:
             on_device = hasattr(model, "calc_study") and rgb_u8
-            frames = None if on_device else condition_frames(nparr)
-            flow_arr = flow_for_study(frames, model, mask_dict, bkgd_comp, conversion_factor,
-                                      nparr_rgb=np.ascontiguousarray(nparr) if on_device else None)
+            if (_submit and not own and on_device and bkgd_comp == "none" and hasattr(model, "submit_study")
+                    and getattr(model, "device_unit_scale", False)):
+                # conditioning now, the solve queued on the engine's lanes: the same call as flow_for_study's device branch, not waited for
+                ticket = model.submit_study(np.ascontiguousarray(nparr), scale=conversion_factor, pad_last=True)
+                collect = lambda: model.wait(ticket)
+            else:
+                frames = None if on_device else condition_frames(nparr)
+                flow_arr = flow_for_study(frames, model, mask_dict, bkgd_comp, conversion_factor,
+                                          nparr_rgb=np.ascontiguousarray(nparr) if on_device else None)
     finally:
         if own:
             model.close()
-    # waveforms (reference :602-620): loaded and validated by the reference's rules unless the caller injected a result dict;
-    # without a valid ECG and a valid arterial waveform the whole block is dropped (waveforms_present = False)
-    waveform_results = {}
-    if include_waveforms:
-        from .waveforms import load_all_waveforms, waveforms_to_write
-        waveform_results = waveforms if waveforms is not None else load_all_waveforms(dcm_path, waveform_folder, config, verbose)
-        if not waveforms_to_write(waveform_results):
-            include_waveforms = False
-    if save_path is not None:
-        job = (save_path, flow_arr, nparr, mask_dict, metadata, waveform_results, patient_id, heart_rate,
-               config, mode, no_saliency, include_waveforms, save_mask_subset)
-        if _defer_save is not None:
-            _defer_save(job)                      # process_folder: the writer thread takes it while the next study is solved
-        else:
-            from .hdf5_out import save_optical_flow_to_hdf5
-            save_optical_flow_to_hdf5(*job)
-    return flow_arr
+    if collect is None:
+        collect = lambda: flow_arr
+
+    def finish():
+        flows = collect()
+        # waveforms (reference :602-620): loaded and validated by the reference's rules unless the caller injected a result dict;
+        # without a valid ECG and a valid arterial waveform the whole block is dropped (waveforms_present = False)
+        waveform_results, with_waveforms = {}, include_waveforms
+        if with_waveforms:
+            from .waveforms import load_all_waveforms, waveforms_to_write
+            waveform_results = waveforms if waveforms is not None else load_all_waveforms(dcm_path, waveform_folder, config, verbose)
+            if not waveforms_to_write(waveform_results):
+                with_waveforms = False
+        if save_path is not None:
+            job = (save_path, flows, nparr, mask_dict, metadata, waveform_results, patient_id, heart_rate,
+                   config, mode, no_saliency, with_waveforms, save_mask_subset)
+            if _defer_save is not None:
+                _defer_save(job)                  # process_folder: the writer stage takes it while the next study is solved
+            else:
+                from .hdf5_out import save_optical_flow_to_hdf5
+                save_optical_flow_to_hdf5(*job)
+        return flows
+    return finish
 
 
 def read_study(path):
@@ -513,7 +540,7 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                    flipLR=False, verbose=True, recalculate=False, no_saliency=True, OF_algo="TVL1", save_mask_subset=None,
                    include_waveforms=False, waveform_folder=None, pixel_spacing=None, frame_rate=None, process_subset=False,
                    file_subset_list=(), *, rank=0, world=1, extensions=("dcm",), reader=read_study, flow_model=None, config=None,
-                   device_id=0, workers="auto", n_readers=None, n_writers=None):
+                   device_id=0, workers="auto", n_readers=None, n_writers=None, studies_in_flight=2):
     """Drop-in for the reference's process_folder (:243-290), same positional signature and the same rules:
       * the folder listing is cut into `nchunks` slices of len // nchunks files, this call takes slice `chunk_index`
         (the remainder files are dropped, as the reference does -- SURVEY.md Appendix C.8);
@@ -529,7 +556,10 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     writer stages in `n_readers` + `n_writers` worker PROCESSES (spawned here, before this call's first GPU call; the mask stage and
     the deflate both hold the interpreter lock, which is why threads bought 3 %), "thread" in one thread each, "auto" takes
     processes when this call creates the flow model itself (no `flow_model`, no `segmentor_model`: nothing in the caller's hands has
-    initialised the GPU yet as far as this function can tell) and more than one study is to do.  Returns the list of (filename, error string)."""
+    initialised the GPU yet as far as this function can tell) and more than one study is to do.  `studies_in_flight` (2): a study's flow solve is
+    submitted to the engine's lanes (tf_submit_seq_rgb) and collected only when the NEXT study's has been submitted, so the GPU goes from one
+    study's solve to the next without waiting for this thread (1 = solve and collect study by study, as rounds 2-4 did).
+    Returns the list of (filename, error string)."""
     os.makedirs(save_folder, exist_ok=True)
     file_list = sorted(os.listdir(dcm_folder))                      # os.listdir order is arbitrary; sorted = same slices on every rank
     errors = []
@@ -555,6 +585,8 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
     use_proc = workers == "process" or (workers == "auto" and flow_model is None and segmentor_model is None)
     state = {"writer": None, "reader_pool": None, "proc": False, "fallback": None, "depth": 1}
     studies = {}                # save_path -> what of a study lives in shared memory until its writer is done
+    begun_ref = []
+    futs = {}
 
     def start_pools(n_todo):
         # worker processes only make sense for more than one study, and they must exist before the first GPU call of this function
@@ -662,6 +694,26 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 pool.shutdown(wait=False, cancel_futures=True)
             state["reader_pool"], state["writer"], state["proc"], state["depth"] = ThreadPoolExecutor(1), ThreadPoolExecutor(1), False, 1
             submit(k)
+        from collections import deque
+        begun = deque()                                               # studies whose solve is submitted and not yet collected
+        begun_ref.append(begun)
+
+        def finish_oldest():
+            filename, save_path, fin = begun.popleft()
+            deferred = len(pending)
+            try:
+                fin()
+            except Exception as e:
+                logger.error(f"Error processing {filename}: {e}")
+                if verbose:
+                    traceback.print_exc()
+                errors.append((filename, f"{type(e).__name__}: {e}"))
+            del fin
+            if len(pending) == deferred:                              # nothing was handed to the writer stage: the study's blocks go now
+                if save_path in studies and not studies[save_path]["blocks"]:
+                    _shm_unlink_names(studies[save_path].get("descs", []))
+                drop_study(save_path)
+            reap(block=False)
         for k in range(min(state["depth"], len(todo))):
             submit(k)
         for k, (filename, stem, save_path) in enumerate(todo):
@@ -669,7 +721,6 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 logger.info(f"Processing file: {filename}...")
             submit(k)                                                 # (already there unless the pools have just been rebuilt)
             submit(k + state["depth"])
-            deferred = len(pending)
             nparr = masks_ahead = echo = None
             try:
                 try:
@@ -693,24 +744,33 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 if model is None:
                     model = flow_model if flow_model is not None else make_flow_model(OF_algo, config, device_id)
                 waveforms = None                                       # process_video loads and validates them (reference :602-620)
-                process_video(os.path.join(dcm_folder, filename), save_path, segmentor_model, verbose=verbose, mode=mode,
-                              bkgd_comp=bkgd_comp, flipLR=flipLR, no_saliency=no_saliency, OF_algo=OF_algo,
-                              save_mask_subset=save_mask_subset, include_waveforms=include_waveforms, waveform_folder=waveform_folder,
-                              config=config, nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, waveforms=waveforms,
-                              flow_model=model, mask_dict=masks_ahead, _defer_save=defer)
+                fin = _process_video_begin(os.path.join(dcm_folder, filename), save_path, segmentor_model, verbose=verbose, mode=mode,
+                                           bkgd_comp=bkgd_comp, flipLR=flipLR, no_saliency=no_saliency, OF_algo=OF_algo,
+                                           save_mask_subset=save_mask_subset, include_waveforms=include_waveforms, waveform_folder=waveform_folder,
+                                           config=config, nparr=nparr, metadata=md, patient_id=pid, heart_rate=hr, waveforms=waveforms,
+                                           flow_model=model, mask_dict=masks_ahead, _defer_save=defer, _submit=studies_in_flight > 1)
+                begun.append((filename, save_path, fin))
+                del fin
             except Exception as e:
                 logger.error(f"Error processing {filename}: {e}")
                 if verbose:
                     traceback.print_exc()
                 errors.append((filename, f"{type(e).__name__}: {e}"))
-            del nparr, masks_ahead, echo
-            if len(pending) == deferred:                              # nothing was handed to the writer stage: the study's blocks go now
                 if save_path in studies and not studies[save_path]["blocks"]:
                     _shm_unlink_names(studies[save_path].get("descs", []))
                 drop_study(save_path)
-            reap(block=False)
+            del nparr, masks_ahead, echo
+            while len(begun) >= max(1, studies_in_flight):
+                finish_oldest()
+        while begun:
+            finish_oldest()
         reap(block=True)
     finally:
+        while begun_ref and begun_ref[0]:                             # (an exception above) submitted solves are collected before the model goes
+            try:
+                begun_ref[0].popleft()[2]()
+            except Exception:
+                pass
         for k, fut in futs.items():                                   # reader results nobody took (an exception above): free their blocks
             try:
                 res = fut.result()

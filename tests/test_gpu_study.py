@@ -27,7 +27,12 @@ for k in range(3):
     np.savez(os.path.join(src, f"st{k}.npz"), nparr=studies[f"st{k}"], pixel_spacing=0.04, frame_rate=50.0, patient_id=f"SYN{k}", heart_rate=60)
 open(os.path.join(src, "bad.npz"), "wb").write(b"garbage")
 errs = process_folder(src, dst, None, nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo="TVL1")
-out = {"errors": errs, "files": sorted(os.listdir(dst)), "ok": True, "layout": None}
+# (default: studies_in_flight=2 -- a study's solve is submitted and collected after the next one's submission; 1 = study by study)
+errs1 = process_folder(src, dst + "1", None, nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",), OF_algo="TVL1", studies_in_flight=1)
+out = {"errors": errs, "errors1": errs1, "files": sorted(os.listdir(dst)), "ok": True, "layout": None, "same1": True}
+for name in studies:
+    with h5py.File(os.path.join(dst, name + ".hdf5"), "r") as a, h5py.File(os.path.join(dst + "1", name + ".hdf5"), "r") as b:
+        out["same1"] = out["same1"] and sorted(a.keys()) == sorted(b.keys()) and all(bool(np.array_equal(a[k][...], b[k][...])) for k in a.keys())
 for name, nparr in studies.items():
     md = {"pixel_spacing": 0.04, "frame_rate": 50.0, "R_wave_data_present": False, "R_times": None}
     ref = process_video(None, None, None, verbose=False, mode="otsu", no_saliency=True, nparr=nparr, metadata=md)
@@ -53,6 +58,7 @@ def test_process_folder_three_studies_on_gpu(tmp_path):
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert [e[0] for e in g["errors"]] == ["bad.npz"]                      # isolated, reported, the walk went on
     assert g["files"] == ["st0.hdf5", "st1.hdf5", "st2.hdf5"] and g["ok"]
+    assert g["same1"] and [e[0] for e in g["errors1"]] == ["bad.npz"]     # studies in flight or one by one: the same files
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_host_side.json")))["hdf5_layout"]["no_waveforms"]
     assert set(g["layout"]) == set(ref) - {"RWaveTime"}
     for k, v in g["layout"].items():
