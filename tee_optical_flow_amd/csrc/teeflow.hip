@@ -11,10 +11,6 @@
 // each tvl1_iter launch publishes "pairs still iterating" to a host-mapped word, which the host reads a few
 // launches later to stop enqueuing a stage -- it never stalls the stream inside the iteration budget.
 #include "teeflow_kernels.hip.h"
-#ifdef TF_EXPERIMENTAL       // the one-wave-per-strip forms of tvl1_iter: measured, tied or lost, kept as experiments
-#include "teeflow_iter_wave.hip.h"
-#include "teeflow_iter3_wave.hip.h"
-#endif
 #include "teeflow_deepflow.hip.h"
 #include "teeflow_sor_rt.hip.h"
 #include "teeflow_analysis.hip.h"
@@ -70,14 +66,6 @@ struct TfKnobs {
     int iter_variant = 2;        // 0 = 64x16 tiles (k_iter), 1 = full-width row strips (k_iter_rows), 2 = row strips with TWO
                                  // iterations per launch (k_iter2_rows); 1 and 2 need W <= max_strip_width (2048) and enough rows*pairs
     int force_ry = 0;            // 0 = floor(256/QX) rows per step
-    int iter_wave = 0;           // 1: batch launches on levels <= 512 px wide take k_iter2_wave (one wave per strip, the row pipeline in registers)
-                                 // instead of k_iter2_rows; 0 = never
-    int wave_max_w = 512;        // widest level the one-wave-per-strip kernels take (<= 512)
-    int wave_minrows = 8;        // k_iter2_wave: shortest strip (rows)
-    int wave_px = 0;             // k_iter2_wave: pixels per lane (4 / 6 / 8); 0 = the narrowest form that covers the level's width
-    int iter_k3 = 0;             // 1: THREE iterations per launch (k_iter3_wave) wherever k_iter2_wave applies and inner_iterations is a multiple of 3
-    int wave_pf = 0;             // k_iter2_wave: 1 = one wave per SIMD with the next row's loads in flight (three register sets), 0 = two or three waves per SIMD
-    int wave_slots = 0;          // k_iter2_wave: resident waves to size the strips for (0 = what the occupancy query says)
     int adaptive_strips = 0;     // strip length from the known active-pair count: measured no gain
     int dynamic_strips = 1;      // strips sized on the device from the exact active-pair count (one round of resident blocks)
     int tile_max_w = 0;          // levels this narrow or narrower always take the tile kernels (experiment: see DESIGN section 8)
@@ -135,7 +123,6 @@ struct tf_handle : TfKnobs {
     float* gxl[MAXLEV] = {}; float* gyl[MAXLEV] = {};   // TF_VARIANT_CUDA: centred gradient of every frame, per level
     int alloc_variant = 0;
     float *cwx = nullptr, *cwy = nullptr, *crho = nullptr;
-    float* zplane = nullptr;            // one level-0 plane of zeros
     StateBufs sb = {};
     PairCtl* ctl = nullptr;
     u64* errs = nullptr; int errstride = 0;
@@ -309,7 +296,7 @@ void free_buffers(tf_handle* h)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (int l = 0; l < MAXLEV; ++l) { F(h->pyr[l]); F(h->gxl[l]); F(h->gyl[l]); }
-    F(h->cwx); F(h->cwy); F(h->crho); F(h->zplane);
+    F(h->cwx); F(h->cwy); F(h->crho);
     for (int k = 0; k < 2; ++k) { F(h->sb.u1[k]); F(h->sb.u2[k]); F(h->sb.p11[k]); F(h->sb.p12[k]); F(h->sb.p21[k]); F(h->sb.p22[k]); }
     F(h->ctl); F(h->errs); F(h->iters_dev);
     F(h->st_u8); F(h->st_flow);
@@ -356,8 +343,6 @@ int ensure_alloc(tf_handle* h, int H, int W, int B)
     h->alloc_variant = h->P.variant;
     const size_t pl = (size_t)h->lv[0].plane * cap * sizeof(float);
     HIPC(h, hipMalloc(&h->cwx, pl)); HIPC(h, hipMalloc(&h->cwy, pl)); HIPC(h, hipMalloc(&h->crho, pl));
-    HIPC(h, hipMalloc(&h->zplane, (size_t)h->lv[0].plane * sizeof(float)));
-    HIPC(h, hipMemsetAsync(h->zplane, 0, (size_t)h->lv[0].plane * sizeof(float), h->stream));
     for (int k = 0; k < 2; ++k) {
         HIPC(h, hipMalloc(&h->sb.u1[k], pl)); HIPC(h, hipMalloc(&h->sb.u2[k], pl));
         HIPC(h, hipMalloc(&h->sb.p11[k], pl)); HIPC(h, hipMalloc(&h->sb.p12[k], pl));
@@ -419,15 +404,6 @@ void strip_shape(const tf_handle* h, const Geom& g, int B, int* R, int* QX, int*
     *R = ry * (int)n;
 }
 
-// pixels per lane of the one-wave-per-strip kernels: the narrowest form that covers the level (float4 / float2 loads must stay inside the padded row)
-int wave_px(const tf_handle* h, const Geom& g)
-{
-    int px = h->wave_px;
-    if (px != 4 && px != 6 && px != 8) px = g.w <= 256 ? 4 : (g.w <= 384 && (g.w + 5) / 6 * 6 <= g.pitch ? 6 : 8);
-    if (px * 64 < g.w) px = 8;
-    if (px == 6 && (g.w + 5) / 6 * 6 > g.pitch) px = 8;
-    return px;
-}
 // launch one two-iteration tvl1_iter step (k_iter2_rows)
 void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int active_hint = 0)
 {
@@ -436,36 +412,6 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
         hipLaunchKernelGGL(k_iter2_tile, dim3((g.w + T2_OW - 1) / T2_OW, (g.h + T2_OH - 1) / T2_OH, B), dim3(256), 0, s, A);
         return;
     }
-#ifdef TF_EXPERIMENTAL
-    if (h->iter_wave && g.w <= h->wave_max_w && B <= 1024) {
-        // one wave per strip: PX pixels per lane (float4 / float2 loads need PX*lanes to stay inside the padded row)
-        const int px = wave_px(h, g);
-        const bool pf = h->wave_pf != 0;
-        void (*kern)(Iter2Args, int, int) =
-            px == 4 ? (pf ? k_iter2_wave<4, true> : k_iter2_wave<4, false>) : px == 6 ? (pf ? k_iter2_wave<6, true> : k_iter2_wave<6, false>)
-                                                                                        : (pf ? k_iter2_wave<8, true> : k_iter2_wave<8, false>);
-        int slots = h->wave_slots;
-        if (slots <= 0) {
-            const size_t key = ((size_t)1 << 40) + (size_t)px * 2 + (pf ? 1 : 0);
-            auto f = h->slots_cache.find(key);
-            if (f == h->slots_cache.end()) {
-                int per_cu = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0);
-                if (per_cu < 1) per_cu = 1;
-                f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
-            }
-            slots = f->second;
-        }
-        int items = 1;
-        for (int n = 1; n <= B; ++n) {
-            int r, sn;
-            strip_rule_min(n, g.h, h->wave_minrows, slots, &r, &sn);
-            if (n * sn > items) items = n * sn;
-        }
-        hipLaunchKernelGGL(kern, dim3(items), dim3(64), 0, s, A, slots, h->wave_minrows);
-        return;
-    }
-#endif
     int R, QX, RY, threads;
     // rows per strip follow the number of pairs known to be still iterating: the thin tail launches of a stage get many
     // short strips (latency of a few steps) instead of a few long ones
@@ -498,44 +444,6 @@ void launch_iter2(tf_handle* h, const Iter2Args& A, int B, hipStream_t s, int ac
     hipLaunchKernelGGL(k_iter2_rows, dim3((g.h + R - 1) / R, 1, B), dim3(threads), shmem, s, A, R, QX, RY, 0);
 }
 
-#ifdef TF_EXPERIMENTAL
-// three iterations per launch: does this stage qualify?  (levels up to 512 px wide, a batch worth the strips, inner % 3 == 0 so that
-// the median cadence stays on a pass boundary, the CPU variant's stop rule)
-bool three_ok(const tf_handle* h, const Geom& g, int B, int inner)
-{
-    return h->iter_k3 && h->iter_wave && h->iter_variant >= 2 && h->P.variant == TF_VARIANT_CPU && inner % 3 == 0 && g.w <= h->wave_max_w && B <= 1024 && rows_ok(h, g, B);
-}
-// launch one three-iteration pass (k_iter3_wave); the caller has checked three_ok()
-void launch_iter3(tf_handle* h, const Iter2Args& A, int B, hipStream_t s)
-{
-    const Geom& g = A.a.g;
-    const int px = wave_px(h, g);
-    void (*kern)(Iter2Args, int, int) = px == 4 ? k_iter3_wave<4> : (px == 6 ? k_iter3_wave<6> : k_iter3_wave<8>);
-    int slots = h->wave_slots;
-    if (slots <= 0) {
-        const size_t key = ((size_t)3 << 40) + (size_t)px;
-        auto f = h->slots_cache.find(key);
-        if (f == h->slots_cache.end()) {
-            int per_cu = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0);
-            if (per_cu < 1) per_cu = 1;
-            f = h->slots_cache.emplace(key, per_cu * h->num_cus).first;
-        }
-        slots = f->second;
-    }
-    int items = 1;
-    for (int n = 1; n <= B; ++n) {
-        int r, sn;
-        strip_rule_min(n, g.h, h->wave_minrows, slots, &r, &sn);
-        if (n * sn > items) items = n * sn;
-    }
-    hipLaunchKernelGGL(kern, dim3(items), dim3(64), 0, s, A, slots, h->wave_minrows);
-}
-
-#else
-inline bool three_ok(const tf_handle*, const Geom&, int, int) { return false; }
-#endif
-
 // launch one tvl1_iter step for pairs [0,B) in the configured kernel form
 void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 {
@@ -553,7 +461,7 @@ void launch_iter(tf_handle* h, const IterArgs& ia, int B, hipStream_t s)
 }
 
 // k_warp_lds is instantiated for a few margins (the staged width is a compile-time constant)
-inline int warp_margin_class(int m) { return m <= 0 ? 0 : (m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 12 ? 12 : 16))); }
+inline int warp_margin_class(int m) { return m <= 0 ? 0 : (m <= 4 ? 4 : (m <= 8 ? 8 : 16)); }
 void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s, const float* gx = nullptr, const float* gy = nullptr)
 {
     const Geom& g = wa.g;
@@ -568,7 +476,6 @@ void launch_warp(tf_handle* h, const WarpArgs& wa, int B, hipStream_t s, const f
     switch (M) {
         case 4: hipLaunchKernelGGL(k_warp_lds<4>, grid, dim3(256), shm, s, wa); break;
         case 8: hipLaunchKernelGGL(k_warp_lds<8>, grid, dim3(256), shm, s, wa); break;
-        case 12: hipLaunchKernelGGL(k_warp_lds<12>, grid, dim3(256), shm, s, wa); break;
         case 16: hipLaunchKernelGGL(k_warp_lds<16>, grid, dim3(256), shm, s, wa); break;
         default: hipLaunchKernelGGL(k_warp, dim3((g.w + 63) / 64, (g.h + 3) / 4, B), dim3(256), 0, s, wa); break;
     }
@@ -612,63 +519,13 @@ int run_stage(tf_handle* h, int l, int wi, int B, int off0, int off1)
     ia.wx = h->cwx; ia.wy = h->cwy; ia.rho = h->crho; ia.sb = h->sb; ia.ctl = h->ctl; ia.err = h->errs;
     ia.errstride = h->errstride; ia.thr_q = thr_q; ia.g = g;
     ia.l_t = (float)(P.lambda * P.theta); ia.theta = (float)P.theta; ia.taut = (float)(P.tau / P.theta);
-    ia.variant = P.variant; ia.thr_d = thr_d; ia.zplane = h->zplane;
+    ia.variant = P.variant; ia.thr_d = thr_d;
     const bool cuda_variant = P.variant == TF_VARIANT_CUDA;      // one loop, no median, stops only after odd iterations
     MedArgs ma;
     ma.sb = h->sb; ma.ctl = h->ctl; ma.err = h->errs; ma.errstride = h->errstride; ma.thr_q = thr_q; ma.g = g;
 
     const dim3 gm((g.w + 63) / 64, (g.h + 15) / 16, 2 * B);
     ia.B = B;
-#ifdef TF_EXPERIMENTAL
-    if (!cuda_variant && three_ok(h, g, B, inner)) {
-        // three iterations per launch; pass index it = 0,3,..,total (the last one can only hold REPLAY strips)
-        int utog = 0, ptog = 0, utog_prev = 0, ptog_prev = 0, pzero_prev = 0;
-        bool stop = false;
-        unsigned checked = h->launch_seq;
-        for (int it = 0; it <= total && !stop; it += 3) {
-            if (it < total && it % inner == 0 && P.median_filtering > 1) {
-                ma.it = it; ma.utog = utog;
-                ProfEv* pm = h->profile ? prof_next(h) : nullptr;
-                if (pm) { pm->level = -5; HIPC(h, hipEventRecord(pm->a, s)); }
-                if (P.median_filtering == 5) hipLaunchKernelGGL(k_median3<5>, gm, dim3(256), 0, s, ma, total);
-                else hipLaunchKernelGGL(k_median3<3>, gm, dim3(256), 0, s, ma, total);
-                if (pm) HIPC(h, hipEventRecord(pm->b, s));
-                ++utog;
-            }
-            const unsigned q = h->launch_seq++;
-            h->slots_host[q % SLOT_RING] = -1;
-            Iter2Args A3;
-            A3.a = ia;
-            A3.a.host_slot = h->slots_dev + q % SLOT_RING;
-            A3.a.it = it; A3.a.utog = utog; A3.a.ptog = ptog; A3.a.pzero = (wi == 0 && it == 0) ? 1 : 0;
-            A3.utog_prev = utog_prev; A3.ptog_prev = ptog_prev; A3.pzero_prev = pzero_prev; A3.total = total;
-            ProfEv* pe = h->profile ? prof_next(h) : nullptr;
-            if (pe) { pe->level = l; pe->warp = wi; pe->it = it; HIPC(h, hipEventRecord(pe->a, s)); }
-            launch_iter3(h, A3, B, s);
-            if (pe) HIPC(h, hipEventRecord(pe->b, s));
-            ++h->iter_launches;
-            utog_prev = utog; ptog_prev = ptog; pzero_prev = A3.a.pzero;
-            ++utog; ++ptog;
-            while (checked <= q) {
-                int v = h->slots_host[checked % SLOT_RING];
-                if (v < 0) {
-                    if (q - checked < (unsigned)h->lag) break;
-                    const double t0 = now_ms();
-                    while ((v = h->slots_host[checked % SLOT_RING]) < 0) {
-                        if (now_ms() - t0 > 20000.0) return fail(h, TF_ERR_HIP, "tvl1_iter launch %u never reported (GPU hang?)", checked);
-                        if (hipStreamQuery(s) == hipSuccess && h->slots_host[checked % SLOT_RING] < 0)
-                            return fail(h, TF_ERR_HIP, "stream drained but launch %u did not report", checked);
-                    }
-                }
-                ++checked;
-                if (v == 0) { stop = true; break; }
-            }
-        }
-        hipLaunchKernelGGL(k_stage_end3, dim3((B + 255) / 256), dim3(256), 0, s, h->errs, h->errstride, h->ctl, h->iters_dev, B,
-                           total, inner, P.median_filtering > 1 ? 1 : 0, thr_q, l, wi, h->nlev, P.warps);
-        return TF_OK;
-    }
-#endif
     const bool two = cuda_variant || (h->iter_variant >= 2 && (rows_ok(h, g, B) || h->tile2) && (inner % 2 == 0));
     if (two) {
         // two iterations per launch; launch index it = 0,2,..,total (the last one can only hold REPLAY blocks)
@@ -1898,26 +1755,14 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
 {
     if (!h || !name) return TF_ERR_INVALID_ARG;
     const std::string n(name);
-#ifndef TF_EXPERIMENTAL
-    if ((n == "iter_variant" && value >= 4) || ((n == "iter_wave" || n == "wave_pf") && value != 0))
-        return fail(h, TF_ERR_UNSUPPORTED, "%s=%d names a one-wave-per-strip form of tvl1_iter: experiments, built only with `make EXPERIMENTAL=1` (DESIGN.md section 4c)", name, value);
-#endif
-    if (n == "iter_variant") {                      // 4 / 5 / 6 = one wave per strip where it applies (4: two or three waves per SIMD; 5: one wave per SIMD
-        h->iter_wave = value >= 4 ? 1 : 0;          // with the next row's loads in flight; 6: that with THREE iterations per launch where inner % 3 == 0);
-        if (value >= 4) h->wave_pf = value >= 5 ? 1 : 0;   // 0 / 1 / 2 name one of the older forms explicitly
-        h->iter_k3 = value == 6 ? 1 : 0;
-        h->iter_variant = value >= 4 ? 2 : value;
+    if (n == "iter_variant") {                      // 0 / 1 / 2 name a form of tvl1_iter (the one-wave-per-strip experiments 4 / 5 / 6 of round 4 are gone: DESIGN.md section 4c)
+        if (value < 0 || value > 2) return fail(h, TF_ERR_UNSUPPORTED, "iter_variant must be 0 (64x16 tiles), 1 (row strips) or 2 (row strips, two iterations per launch), got %d", value);
+        h->iter_variant = value;
     }
     else if (n == "strip_blocks") h->strip_blocks = value > 0 ? value : 2048;
     else if (n == "lag") h->lag = value < 0 ? DEFAULT_LAG : (value < SLOT_RING / 2 ? value : SLOT_RING / 2);   // 0 = wait for every launch's report (it is published at the launch's start); unread slots must never be overwritten
     else if (n == "min_rows_work") h->min_rows_work = value;
     else if (n == "force_ry") h->force_ry = value;
-    else if (n == "iter_wave") h->iter_wave = value;
-    else if (n == "wave_minrows") h->wave_minrows = value < 1 ? 1 : value;
-    else if (n == "wave_px") h->wave_px = value;
-    else if (n == "wave_max_w") h->wave_max_w = value < 0 ? 0 : (value > 512 ? 512 : value);
-    else if (n == "wave_slots") h->wave_slots = value;
-    else if (n == "wave_pf") h->wave_pf = value ? 1 : 0;
     else if (n == "adaptive_strips") h->adaptive_strips = value;
     else if (n == "dynamic_strips") h->dynamic_strips = value;
     else if (n == "slots") h->slots_override = value;
@@ -1956,16 +1801,6 @@ TF_API int tf_set_tuning(tf_handle* h, const char* name, int value)
     return TF_OK;
 }
 
-#ifdef TF_WAVE_TIMING
-extern "C" __attribute__((visibility("default"))) int tf_dbg_step_times(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_t), sizeof(unsigned long long) * 2 * 96);
-}
-extern "C" __attribute__((visibility("default"))) int tf_dbg_wave_times(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 4 * 4096);
-}
-#endif
 #ifdef TF_COOP_TIMING
 extern "C" __attribute__((visibility("default"))) int tf_dbg_coop_times(unsigned long long* out)
 {
@@ -1995,13 +1830,6 @@ TF_API long long tf_dbg_counter(tf_handle* h, const char* name)
             std::lock_guard<std::mutex> lk(h->pool->m);
             v = n == "queue_units_done" ? h->q_units_done : n == "queue_units_skipped" ? h->q_units_skipped : n == "queue_units_failed" ? h->q_units_failed : n == "queue_outstanding" ? h->pool->outstanding : (long long)h->pool->lanes.size();
         }
-    }
-    else if (n == "experimental") {
-#ifdef TF_EXPERIMENTAL
-        v = 1;
-#else
-        v = 0;
-#endif
     }
     else if (n == "coop_occ16") v = h->coop_occ16;
     else if (n == "coop_occ8") v = h->coop_occ8;
@@ -2841,9 +2669,9 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
         return TF_ERR_INVALID_ARG;
     HIPC(h, hipSetDevice(h->dev));
     const Geom g = make_geom(w, hgt);
-    DBuf cx, cy, cr, cz, s[12];
+    DBuf cx, cy, cr, s[12];
     int rc;
-    if ((rc = dbg_up(h, cx, I1wx, g)) || (rc = dbg_up(h, cy, I1wy, g)) || (rc = dbg_up(h, cr, rho_c, g)) || (rc = dbg_up(h, cz, nullptr, g))) return rc;
+    if ((rc = dbg_up(h, cx, I1wx, g)) || (rc = dbg_up(h, cy, I1wy, g)) || (rc = dbg_up(h, cr, rho_c, g))) return rc;
     float* hostp[6] = {u1, u2, p11, p12, p21, p22};
     for (int k = 0; k < 6; ++k) {
         if ((rc = dbg_up(h, s[2 * k], hostp[k], g)) || (rc = dbg_up(h, s[2 * k + 1], nullptr, g))) return rc;
@@ -2854,7 +2682,7 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     HIPC(h, hipMalloc(&errs, (size_t)(nsteps + 1) * sizeof(u64)));
     HIPC(h, hipMemsetAsync(errs, 0, (size_t)(nsteps + 1) * sizeof(u64), h->stream));
     IterArgs ia = {};
-    ia.wx = cx.p; ia.wy = cy.p; ia.rho = cr.p; ia.zplane = cz.p;
+    ia.wx = cx.p; ia.wy = cy.p; ia.rho = cr.p;
     for (int k = 0; k < 2; ++k) {
         ia.sb.u1[k] = s[0 + k].p; ia.sb.u2[k] = s[2 + k].p; ia.sb.p11[k] = s[4 + k].p;
         ia.sb.p12[k] = s[6 + k].p; ia.sb.p21[k] = s[8 + k].p; ia.sb.p22[k] = s[10 + k].p;
@@ -2863,16 +2691,6 @@ TF_API int tf_dbg_iterate(tf_handle* h, const float* I1wx, const float* I1wy, co
     ia.l_t = (float)(h->P.lambda * h->P.theta); ia.theta = (float)h->P.theta; ia.taut = (float)(h->P.tau / h->P.theta);
     const bool two = h->iter_variant == 2 && (rows_ok(h, g, 1) || h->tile2) && nsteps % 2 == 0;
     int launches = 0;
-#ifdef TF_EXPERIMENTAL
-    if (three_ok(h, g, 1, 3) && nsteps % 3 == 0 && nsteps > 0) {
-        for (int it = 0; it < nsteps; it += 3, ++launches) {
-            Iter2Args A3;
-            A3.a = ia; A3.a.it = it; A3.a.utog = launches; A3.a.ptog = launches; A3.a.pzero = (p_is_zero && it == 0) ? 1 : 0;
-            A3.utog_prev = A3.ptog_prev = A3.pzero_prev = 0; A3.total = nsteps;
-            launch_iter3(h, A3, 1, h->stream);
-        }
-    } else
-#endif
     if (two) {
         for (int it = 0; it < nsteps; it += 2, ++launches) {
             Iter2Args A2;

@@ -610,7 +610,6 @@ struct IterArgs {
     int B;
     int variant;      // 0 = cv2.optflow CPU DualTVL1; 1 = cv2.cuda.OpticalFlowDual_TVL1 stop rule
     double thr_d;     // epsilon^2 * area in double: the CUDA class keeps scaledEpsilon, error and prevError in double (variant 1)
-    const float* zplane;   // a level-0 plane of zeros (k_iter2_wave reads the dual variable from it at the first launch of a level)
 };
 
 // Block 0 / wave 0 tells the host how many of the B pairs enter iteration `it` active, through fine-grained

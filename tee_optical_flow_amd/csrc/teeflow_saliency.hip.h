@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void k_sal_scales(const uint8_t* __restrict__ 
         const float* If = I + (size_t)f * (H + 1) * (W + 1);
         const int nbs[6] = {12, 24, 48, 28, 56, 112};
         const int yend = min(H, (int)(blockIdx.y + 1) * SAL_ROWS);
-        for (int y = blockIdx.y * SAL_ROWS; y < yend; ++y) {
+#pragma unroll 1
+        for (int y = blockIdx.y * SAL_ROWS; y < yend; ++y) {            // (unrolled eightfold this kernel was 52 KB of code)
             const size_t i = ((size_t)f * H + y) * W + x;
             const int g = gray[i];
             int son = 0, soff = 0;

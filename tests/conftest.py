@@ -41,9 +41,3 @@ def engine():
     yield eng
     eng.close()
 
-
-def needs_experimental(eng, variant):
-    """iter_variant 4 / 5 / 6 (the one-wave-per-strip forms of tvl1_iter) exist only in a library built with `make EXPERIMENTAL=1`
-    (tee_optical_flow_amd/csrc/Makefile); the shipped build refuses the knob and those cases are skipped."""
-    if variant >= 4 and eng.counter("experimental") != 1:
-        pytest.skip("iter_variant >= 4 needs the experimental build (make -C tee_optical_flow_amd/csrc EXPERIMENTAL=1)")

@@ -5,7 +5,6 @@ against the CPU oracle on a spread sample."""
 import numpy as np
 import pytest
 
-from tests.conftest import needs_experimental
 
 pytestmark = pytest.mark.gpu
 
@@ -134,37 +133,3 @@ def test_config4_batch_128_pairs_512_deepflow_every_sor_form_agrees(oracle):
             assert np.array_equal(flows[b], oracle.deepflow_calc(I0s[b], I1s[b])), f"pair {b}: not bit-identical to the oracle"
     finally:
         eng.close()
-
-
-@pytest.mark.parametrize("variant", [4, 5, 6])
-@pytest.mark.parametrize("n,H,W,params", [
-    (24, 300, 500, {}),                                                      # levels 500 / 400 px (8 px per lane), 320 (6), 256 / 205 (4)
-    (20, 160, 372, {"inner_iterations": 9, "outer_iterations": 5}),           # 372 px: 6 px per lane needs 372 <= pitch; inner % 3 == 0
-    (16, 512, 512, {"inner_iterations": 6, "outer_iterations": 3, "warps": 2, "nscales": 3}),
-])
-def test_one_wave_per_strip_forms_in_mixed_batches(oracle, variant, n, H, W, params):
-    """The round-4 forms of tvl1_iter (iter_variant 4: k_iter2_wave at two or three waves per SIMD; 5: one wave per SIMD with the next
-    row's loads in flight in hidden accumulation registers; 6: k_iter3_wave, three iterations per pass, REPLAY of one or two) on batches
-    whose pairs stop at very different iterations -- every pixels-per-lane instantiation, partially active launches, both lane counts:
-    identical flows and executed iteration counts to the default kernel, and to the oracle on a sample."""
-    I0s, I1s = _mixed_pairs(n, H, W, seed0=700)
-    eng = _engine(n, **params)
-    try:
-        needs_experimental(eng, variant)
-        f0, it0 = _run(eng, I0s, I1s, lanes=1)                                # default form
-        eng.set_tuning("iter_variant", variant)
-        eng.set_tuning("min_rows_work", 0)
-        f1, it1 = _run(eng, I0s, I1s, lanes=1)
-        assert np.array_equal(it0, it1) and np.array_equal(f0, f1)
-        f2, it2 = _run(eng, I0s, I1s, lanes=2)
-        assert np.array_equal(it0, it2) and np.array_equal(f0, f2)
-        if params.get("inner_iterations", 30) % 3 == 0:
-            n_it = it0[..., 0]
-            assert (n_it % 3 == 1).any() and (n_it % 3 == 2).any() and (n_it % 3 == 0).any(), "every residue of the stop iteration mod 3 should occur"
-        op = oracle.default_params(**params)
-        for b in (3, n - 1):
-            ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], op, return_iters=True)
-            assert np.array_equal(it1[b], ref_it[:nl]) and np.array_equal(f1[b], ref), f"pair {b}"
-    finally:
-        eng.close()
-

@@ -6,7 +6,6 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests.conftest import needs_experimental
 
 pytestmark = pytest.mark.gpu
 
@@ -91,15 +90,14 @@ def test_median_bit_exact(engine, oracle, shape, ksize):
 
 @pytest.mark.parametrize("shape", [(64, 64), (97, 131), (210, 210), (15, 60), (16, 61), (31, 121), (512, 512), (3, 1021)])
 @pytest.mark.parametrize("pzero", [0, 1])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
     """k steps of the fused tvl1_iter kernel == k oracle iterations (state AND exact error sums), for all four
     kernel forms: 64x16 tiles, full-width row strips, row strips with two iterations per launch, tiles with two
     iterations per launch (variant 3 = variant 2 on a launch too small for the strips)."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
-    needs_experimental(engine, variant)
-    engine.set_tuning("iter_variant", variant if variant >= 4 else min(variant, 2))
+    engine.set_tuning("iter_variant", min(variant, 2))
     engine.set_tuning("min_rows_work", 0 if variant != 3 else 1 << 30)   # strips even for this single small image | tiles
     try:
         _iterate_case(engine, oracle, L, shape, pzero)
@@ -108,7 +106,7 @@ def test_iterate_bit_exact(engine, oracle, shape, pzero, variant):
         engine.set_tuning("min_rows_work", 8192)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant):
     """The dual/primal updates where real echo frames put them: next to exactly-black regions the flow and the dual
     variable decay geometrically through 1e-30 into the denormal range.  State, warp constants and rho are scaled by
@@ -116,7 +114,6 @@ def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant
     the sign of zero and every denormal count)."""
     from tee_optical_flow_amd import _lib
     L = _lib.load()
-    needs_experimental(engine, variant)
     h, w = 96, 384
     rng = np.random.default_rng(21)
     k = (np.arange(w) // 8).astype(np.float64)                       # 0 .. 47
@@ -133,7 +130,7 @@ def test_iterate_tiny_zero_and_denormal_values_bit_exact(engine, oracle, variant
     wx[40:50] = rng.uniform(-20, 20, (10, w)).astype(np.float32)     # ordinary gradients over tiny flow
     wy[40:50] = rng.uniform(-20, 20, (10, w)).astype(np.float32)
     grad = wx * wx + wy * wy
-    engine.set_tuning("iter_variant", variant if variant >= 4 else min(variant, 2))
+    engine.set_tuning("iter_variant", min(variant, 2))
     engine.set_tuning("min_rows_work", 0 if variant != 3 else 1 << 30)
     try:
         nsteps = 6

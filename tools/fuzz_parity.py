@@ -36,10 +36,7 @@ def main():
         if rng.random() < 0.5:
             eng.set_tuning("min_rows_work", 0)                # force the strip kernels even for tiny work
         eng.set_tuning("lanes", int(rng.choice([1, 2])))
-        iv = int(rng.choice([6, 6, 5, 4, 2, 1, 0]))           # two iterations per launch on strips / tiles, one per launch, 64x16 tiles
-        if iv >= 4 and eng.counter("experimental") != 1:
-            iv = 2                                             # the one-wave-per-strip forms exist only in a `make EXPERIMENTAL=1` library
-        eng.set_tuning("iter_variant", iv)
+        eng.set_tuning("iter_variant", int(rng.choice([2, 2, 1, 0])))      # two iterations per launch on strips / tiles, one per launch, 64x16 tiles
         eng.set_tuning("queue_lanes", int(rng.choice([-1, -1, 0, 2])))       # calls above the capacity: lanes take sub-batches from the queue / contiguous parts
         flows = eng.calc_pairs(I0s, I1s)
         iters = eng.last_iters()
