@@ -98,7 +98,10 @@ def main():
         js = os.path.join(src, f"{tag}_bench_{name}.json")
         if os.path.exists(js) and os.path.getsize(js):
             shutil.copy(js, os.path.join(DST, f"{tag}_bench_{name}.json"))
-    for name in (f"{tag}_bench_pmc.json", f"{tag}_launch_profile_b64.txt", f"{tag}_ablate_probe.txt"):
+    st = glob.glob(os.path.join(src, "saliency", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(DST, f"{tag}_saliency_kernel_stats.csv"))
+    for name in (f"{tag}_bench_pmc.json", f"{tag}_launch_profile_b64.txt", f"{tag}_ablate_probe.txt", f"{tag}_saliency_bench.txt", f"{tag}_queue_forms.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(DST, name))
