@@ -187,3 +187,42 @@ def test_deepflow_through_the_queue(oracle):
             assert np.array_equal(f1[b], oracle.deepflow_calc(I0s[b], I1s[b]))
     finally:
         eng.close()
+
+
+PROBE = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, ROOT)
+import tee_optical_flow_amd as T
+from tests.test_gpu_batches import _mixed_pairs
+I0s, I1s = _mixed_pairs(40, 64, 88, seed0=11)
+eng = T.DenseFlow(device_id=0, max_batch=16)
+f = np.array(eng.calc_pairs(I0s, I1s))                       # 3 units on 3 lanes
+one = np.array(eng.calc_pairs(I0s[:16], I1s[:16]))           # one sub-batch: the handle and its twin
+print(json.dumps({"retries": eng.counter("stream_retries"), "serialised": eng.counter("streams_serialised"), "lanes": eng.counter("queue_lanes"),
+                  "same": bool(np.array_equal(f[:16], one)), "sum": float(np.abs(f).sum())}))
+eng.close()
+"""
+
+
+@pytest.mark.parametrize("queues", ["2", "4", "8"])
+def test_lanes_look_for_streams_that_run_beside_each_other(queues):
+    """HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues and serialises streams that share one.  With 8 or 4 queues the three
+    lanes end up on streams that run concurrently (the probe may have to drop a few); with 2 they cannot, and the library says so
+    instead of assuming.  Flows do not depend on any of it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", PROBE.replace("ROOT", repr(root))], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "GPU_MAX_HW_QUEUES": queues})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    g = json.loads(r.stdout.strip().splitlines()[-1])
+    assert g["lanes"] == 3 and g["same"]
+    if queues == "2":
+        assert g["serialised"] == 1 and g["retries"] >= 8
+    else:
+        assert g["serialised"] == 0
+    test_lanes_look_for_streams_that_run_beside_each_other.sums = getattr(test_lanes_look_for_streams_that_run_beside_each_other, "sums", set()) | {g["sum"]}
+    assert len(test_lanes_look_for_streams_that_run_beside_each_other.sums) == 1
