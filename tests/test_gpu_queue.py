@@ -226,3 +226,43 @@ def test_lanes_look_for_streams_that_run_beside_each_other(queues):
         assert g["serialised"] == 0
     test_lanes_look_for_streams_that_run_beside_each_other.sums = getattr(test_lanes_look_for_streams_that_run_beside_each_other, "sums", set()) | {g["sum"]}
     assert len(test_lanes_look_for_streams_that_run_beside_each_other.sums) == 1
+
+
+@pytest.mark.parametrize("algo,cap", [("TVL1", 5), ("deepflow", 4)])
+def test_queue_stress_random_jobs_random_collection_order(algo, cap):
+    """Forty jobs of random sizes (1 .. 3.x sub-batches), submitted in bursts with synchronous calls in between and collected in random
+    order: every job's flows (and DualTVL1 iteration counts) equal those of the same pairs solved alone by a second engine."""
+    import tee_optical_flow_amd as T
+    rng = np.random.default_rng(20260105)
+    H, W = (48, 72) if algo == "TVL1" else (64, 96)
+    pool0, pool1 = _mixed(60, H, W, seed0=7000)
+    eng = T.DenseFlow(device_id=0, max_batch=cap, algo=algo)
+    ref = T.DenseFlow(device_id=0, max_batch=64, algo=algo)
+    ref.set_tuning("queue_lanes", 0)
+    try:
+        want_all = np.array(ref.calc_pairs(pool0, pool1))
+        it_all = ref.last_iters().copy() if algo == "TVL1" else None
+        open_jobs = {}
+        done = 0
+        for k in range(40):
+            n = int(rng.integers(1, 3 * cap + 3))
+            a = int(rng.integers(0, 60 - n + 1))
+            open_jobs[eng.submit_pairs(pool0[a:a + n], pool1[a:a + n])] = (a, n)
+            if rng.random() < 0.25:                                        # a synchronous call queues behind what is in flight
+                b, m = int(rng.integers(0, 50)), int(rng.integers(1, 2 * cap))
+                assert np.array_equal(np.array(eng.calc_pairs(pool0[b:b + m], pool1[b:b + m])), want_all[b:b + m])
+            while open_jobs and (len(open_jobs) > 6 or rng.random() < 0.3):
+                t = list(open_jobs)[int(rng.integers(0, len(open_jobs)))]
+                a, n = open_jobs.pop(t)
+                got = eng.wait(t)
+                assert np.array_equal(got, want_all[a:a + n]), f"job {t}: pairs {a}..{a + n - 1}"
+                if it_all is not None:
+                    assert np.array_equal(eng.last_iters(), it_all[a:a + n])
+                done += 1
+        for t, (a, n) in open_jobs.items():
+            assert np.array_equal(eng.wait(t), want_all[a:a + n])
+            done += 1
+        assert done == 40 and eng.counter("queue_outstanding") == 0 and eng.counter("queue_units_failed") == 0
+    finally:
+        eng.close()
+        ref.close()
