@@ -58,10 +58,11 @@ def main():
         N = int(rng.integers(1, 6))
         ch = int(rng.choice([1, 3, 3]))
         a = draw(rng, N, H, W, ch)
-        got = eng.saliency_frames(a if ch == 3 else a[..., 0])
-        ref = np.stack([O.saliency_fine_grained(f if ch == 3 else f[..., 0]) for f in a])
-        ok = np.array_equal(got, ref)
-        print(f"case {c}: {N} x {H}x{W}x{ch}: {'ok' if ok else 'FAIL ' + str(int(np.count_nonzero(got != ref))) + ' bytes differ'}", flush=True)
+        dt = np.float32 if rng.random() < 0.5 else np.uint8          # the CV_32F map in [0,1] (default hand-over) or the 8-bit map
+        got = eng.saliency_frames(a if ch == 3 else a[..., 0], dtype=dt)
+        ref = np.stack([O.saliency_fine_grained(f if ch == 3 else f[..., 0], dt) for f in a])
+        ok = got.dtype == ref.dtype and np.array_equal(got.view(np.uint32 if dt == np.float32 else np.uint8), ref.view(np.uint32 if dt == np.float32 else np.uint8))
+        print(f"case {c}: {N} x {H}x{W}x{ch} {np.dtype(dt).name}: {'ok' if ok else 'FAIL ' + str(int(np.count_nonzero(got != ref))) + ' values differ'}", flush=True)
         bad += not ok
     eng.close()
     print(f"{cases - bad}/{cases} cases identical in {time.time() - t0:.0f} s")
