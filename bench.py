@@ -454,6 +454,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     eng.calc_pairs_device(p0, p1, B, H, W, flows[0].data_ptr())          # set-up, not a step: every lane allocates its buffers
     run_steps(0, warmup)
     fence()
+    units0 = eng.counter("queue_units_done")
     t0 = time.perf_counter()
     acc = {"iter_ms": 0.0, "iter_bytes": 0.0, "iter_launches": 0, "total_bytes": 0.0, "inner": 0, "outer": 0, "ms_device": 0.0,
            "timed_iter_bytes": 0.0, "sor_px": 0.0}
@@ -469,6 +470,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     last_buf = (warmup + steps - 1) % NBUF
     last_flow = flows[last_buf]
     queue_lanes = eng.counter("queue_lanes")
+    units_per_step = (eng.counter("queue_units_done") - units0) / max(steps, 1) if (B > SUB or E > 1) else 1     # what the library cut a step into
     lane_streams = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_tried_and_dropped": eng.counter("stream_retries"),
                     "lanes_serialised_on_a_shared_hardware_queue": bool(eng.counter("streams_serialised"))}
     gather_ok = None
@@ -684,7 +686,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{B} independent {H}x{W} u8 frame pairs per GPU per step (BASELINE configs[1] pair, "
-                                   f"{len(subs)} sub-batch(es) of configs[2]'s per-GPU shard size {SUB}) in ONE call of the boundary, speckle-warp v1 seeds rank*B..; "
+                                   f"{units_per_step:g} sub-batch(es) of at most configs[2]'s per-GPU shard size {SUB}) in ONE call of the boundary, speckle-warp v1 seeds rank*B..; "
                                    + ("DualTVL1 all defaults, lambda 0.15, 5 scales x0.8, 5 warps, eps 0.01, 30x10 iterations, 5x5 median; "
                                       if algo == "TVL1" else
                                       "DeepFlow all defaults (BASELINE configs[3]): sigma 0.6, x0.95 pyramid (60 levels), 5 fixed-point x 25 SOR, omega 1.6; ")
@@ -692,7 +694,7 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
                                    + ("RCCL all-gather of (u,v) overlapped with the next step" if world > 1 else "single GPU, no collective"),
                        "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}",
                        "calls_per_step": 1, "boundary_call": ("tf_calc_pairs_device (synchronous)" if E == 1 else f"tf_submit_pairs_device / tf_wait, {E} steps in flight"),
-                       "sub_batch_pairs": SUB, "sub_batches_per_step": len(subs),
+                       "sub_batch_capacity_pairs": SUB, "sub_batches_per_step": units_per_step, "pairs_per_sub_batch": B / units_per_step,
                        # what overlaps inside the library (include/teeflow.h "Sub-batches and lanes"): lanes that take whole sub-batches from a queue
                        "steps_in_flight": E, "library_queue_lanes": queue_lanes if B > SUB or E > 1 else 0, "lane_streams": lane_streams,
                        "lanes_per_sub_batch_call": a.lanes if B <= SUB and E == 1 else (a.lanes if algo != "TVL1" else 1)},

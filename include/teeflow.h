@@ -19,7 +19,8 @@
  * device may be driven from several host threads at once.
  *
  * Sub-batches and lanes.  A handle solves up to max_batch (128) pairs at a time.  A call that holds more
- * -- tf_calc_pairs with 1024 pairs, tf_calc_seq on a 1025-frame study -- is cut into sub-batches that the
+ * -- tf_calc_pairs with 1024 pairs, tf_calc_seq on a 1025-frame study -- is cut into equal sub-batches (as few as fit, a multiple of
+ * the lane count of them: 1024 pairs = 9 x 114) that the
  * handle's LANES (engines of their own inside the library: stream, buffers, host thread; three for
  * DualTVL1, one for DeepFlow) take from a queue one at a time: a lane that has finished a sub-batch starts
  * the next at once, so one sub-batch's tail (few pairs still iterating) runs under the others' full
@@ -273,7 +274,7 @@ int tf_device_count(void);
  * 128x32 regions for small batches, 0 = never), "sor_coop_small" (0 = small batches keep the tiled form), "sor_coop_s" (sweeps between two exchanges), "sor_coop_min_util" (per cent of its CUs such a launch must fill, else tiled), "df_fuse_ds" (form of the data/smoothness kernel).
  * Both: "lanes" (contiguous parts a call of at most one sub-batch is split into, joined at its end), "queue_lanes" (lanes that take whole
  * sub-batches of larger calls and of tf_submit_* jobs from the queue: -1 = 3 for DualTVL1, 1 for DeepFlow [default]; 0 = no queue, every call is
- * split in contiguous parts as in rounds 1-4), "queue_unit" (pairs per queued sub-batch, 0 = max_batch). */
+ * split in contiguous parts as in rounds 1-4), "queue_unit" (pairs per queued sub-batch; 0 = equal sub-batches of at most max_batch pairs, a multiple of the lane count of them). */
 int tf_set_tuning(tf_handle* h, const char* name, int value);
 /* counters of the handle for tests and tools: "coop_launches" (launches of the co-resident SOR form since the handle was made),
  * "coop_aborts" (calls repeated with the tiled form because such a launch gave up waiting), "coop_disabled"; "queue_jobs", "queue_units_done",

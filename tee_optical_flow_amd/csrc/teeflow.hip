@@ -190,7 +190,7 @@ struct tf_handle : TfKnobs {
     double warp_ms = 0, median_ms = 0;   // profiling: summed launch durations per stage of the last call
     // ---- engine lanes that pull whole sub-batches from a queue (calc_entry, tf_submit_*) ----
     int queue_lanes = -1;        // -1 = per algorithm (3 DualTVL1, 1 DeepFlow); 0 = never: every call is cut in contiguous parts that are joined at its end
-    int queue_unit = 0;          // pairs per queue unit (0 = max_batch, the sub-batch size)
+    int queue_unit = 0;          // pairs per queue unit (0 = equal units of at most max_batch pairs, a multiple of the lane count of them)
     int queue_test_fail_unit = -1;   // tests: the lane that takes this unit of the next queued job reports a failure instead of solving it
     bool is_lane = false;        // this handle is a queue lane of another handle (an engine of its own: stream, buffers, host thread, its own twins)
     LanePool* pool = nullptr;
@@ -1455,6 +1455,15 @@ int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uin
     j->src_f32 = h->src_f32; j->P = h->P; j->DP = h->DP; j->knobs = static_cast<const TfKnobs&>(*h);
     j->split_lanes = deep ? h->lanes : 1;
     j->unit = queue_unit_pairs(h);
+    if (h->queue_unit <= 0) {
+        // Equal units, a multiple of the lane count of them: 512 pairs as 4 x 128 leave two lanes idle while the third solves its second
+        // unit; as 6 x 86 every lane gets two.  200 pairs: 2629-2646 pairs/s as 128 + 72, 2772-2796 as 3 x 67; 448: 2734-2786 -> 2780-2824;
+        // 640: 2867-2877 -> 2915-2922; 1024 (8 x 128 against 9 x 114): a tie (gpurun_out/r5o).  Smaller units cost a few per cent each
+        // (6 x 64 for 384 pairs: - 5 %), which is why the count is the SMALLEST multiple of the lanes whose units fit a sub-batch.
+        const int L = queue_lane_count(h) > 0 ? queue_lane_count(h) : 1;
+        const int U = L * ((n_pairs + L * j->unit - 1) / (L * j->unit));
+        j->unit = (n_pairs + U - 1) / U;
+    }
     j->n_units = (n_pairs + j->unit - 1) / j->unit;
     j->fail_unit = h->queue_test_fail_unit; h->queue_test_fail_unit = -1;
     memset(&j->st, 0, sizeof j->st);

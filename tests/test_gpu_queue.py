@@ -31,14 +31,15 @@ def test_queue_gives_the_split_forms_flows_and_iteration_order(oracle, n, cap, u
         eng.set_tuning("queue_lanes", -1)
         eng.set_tuning("queue_unit", unit)
         f1 = np.array(eng.calc_pairs(I0s, I1s)); it1 = eng.last_iters().copy()
-        u = unit or cap
+        # unit 0: equal units, the smallest multiple of the three lanes of them that fit a sub-batch (53 pairs, 16 per sub-batch: 6 x 9)
+        u = unit or -(-n // (3 * -(-n // (3 * cap))))
         assert eng.counter("queue_jobs") == 1 and eng.counter("queue_lanes") == 3
         assert eng.counter("queue_units_done") == -(-n // u) and eng.counter("queue_outstanding") == 0
         assert eng.last_stats["n_pairs"] == n and eng.last_stats["inner_iters_total"] == int(it0[..., 0].sum())
         assert np.array_equal(it0, it1) and np.array_equal(f0, f1)
         spread = it0[..., 0].sum(axis=(1, 2))
         assert spread.max() > 1.5 * spread.min(), "the batch should mix fast and slow pairs"
-        for b in (0, 3, 5, cap - 1, cap, n - 1):                          # first / last of a unit, a zero-flow pair, an unrelated pair
+        for b in (0, 3, 5, u - 1, u, n - 1):                              # first / last of a unit, a zero-flow pair, an unrelated pair
             ref, ref_it, nl = oracle.tvl1_calc(I0s[b], I1s[b], return_iters=True)
             assert np.array_equal(it1[b], ref_it[:nl]) and np.array_equal(f1[b], ref), f"pair {b}"
         for lanes in (1, 2, 5):                                           # any lane count, same bits
@@ -59,9 +60,9 @@ def test_queue_sequence_mode_units_share_their_boundary_frame(oracle):
         f0 = np.array(eng.calc_batch(frames, scale=1.5)); it0 = eng.last_iters().copy()
         eng.set_tuning("queue_lanes", -1)
         f1 = np.array(eng.calc_batch(frames, scale=1.5))
-        assert eng.counter("queue_units_done") == 4                        # 49 pairs: 16 + 16 + 16 + 1
+        assert eng.counter("queue_units_done") == 6                        # 49 pairs, 16 per sub-batch, three lanes: 5 x 9 + 4
         assert np.array_equal(f0, f1) and np.array_equal(it0, eng.last_iters())
-        for i in (0, 15, 16, 47, 48):
+        for i in (0, 8, 9, 44, 48):
             assert np.array_equal(f1[i], oracle.tvl1_calc(frames[i], frames[i + 1]) * np.float32(1.5))
     finally:
         eng.close()
@@ -72,6 +73,7 @@ def test_a_failing_sub_batch_drains_every_lane_before_the_call_returns(oracle):
     I0s, I1s = _mixed(64, 72, 96, seed0=40)
     eng = _engine(16)
     try:
+        eng.set_tuning("queue_unit", 16)                                   # four units of 16 on three lanes
         good = np.array(eng.calc_pairs(I0s, I1s)); it = eng.last_iters().copy()
         done0 = eng.counter("queue_units_done")
         eng.set_tuning("queue_test_fail_unit", 1)                          # the lane that takes unit 1 reports a failure instead of solving it
