@@ -1443,7 +1443,8 @@ int pool_ensure(tf_handle* h)
 }
 
 // fills the job from the handle's current settings and hands it to the lanes
-int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, int device)
+int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uint8_t* in1, int n_pairs, int H, int W, float scale, float* flow_out, int device,
+                 bool balance)
 {
     const bool deep = h->P.algo == TF_ALGO_DEEPFLOW;
     int rc = deep ? df_validate(h, h->DP) : validate_params(h, h->P);
@@ -1455,15 +1456,15 @@ int queue_submit(tf_handle* h, QJob* j, Mode mode, const uint8_t* in0, const uin
     j->src_f32 = h->src_f32; j->P = h->P; j->DP = h->DP; j->knobs = static_cast<const TfKnobs&>(*h);
     j->split_lanes = deep ? h->lanes : 1;
     j->unit = queue_unit_pairs(h);
-    if (h->queue_unit <= 0) {
-        // Equal units, a multiple of the lane count of them: 512 pairs as 4 x 128 leave two lanes idle while the third solves its second
+    if (h->queue_unit <= 0 && balance) {
+        // A synchronous call on an empty queue ends with its lanes draining.  Equal units, a multiple of the lane count of them: 512 pairs as 4 x 128 leave two lanes idle while the third solves its second
         // unit; as 6 x 86 every lane gets two.  200 pairs: 2629-2646 pairs/s as 128 + 72, 2772-2796 as 3 x 67; 448: 2734-2786 -> 2780-2824;
         // 640: 2867-2877 -> 2915-2922; 1024 (8 x 128 against 9 x 114): a tie (gpurun_out/r5o).  Smaller units cost a few per cent each
         // (6 x 64 for 384 pairs: - 5 %), which is why the count is the SMALLEST multiple of the lanes whose units fit a sub-batch.
         const int L = queue_lane_count(h) > 0 ? queue_lane_count(h) : 1;
         const int U = L * ((n_pairs + L * j->unit - 1) / (L * j->unit));
         j->unit = (n_pairs + U - 1) / U;
-    }
+    }   // (a submitted job's last units run beside the next job's first: whole sub-batches, which are the more efficient units)
     j->n_units = (n_pairs + j->unit - 1) / j->unit;
     j->fail_unit = h->queue_test_fail_unit; h->queue_test_fail_unit = -1;
     memset(&j->st, 0, sizeof j->st);
@@ -1519,7 +1520,7 @@ int calc_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
     if (!can_queue || (!busy && n_pairs <= queue_unit_pairs(h)))
         return calc_split(h, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, st);
     QJob j;
-    int rc = queue_submit(h, &j, mode, in0, in1, n_pairs, H, W, scale, flow_out, device);
+    int rc = queue_submit(h, &j, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, !busy);
     if (rc) return rc;
     return queue_finish(h, &j, st);
 }
@@ -1543,7 +1544,7 @@ int submit_entry(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1
         if (rc) { delete j; return rc; }
         j->st = st; j->n_pairs = n_pairs; j->nlev = h->last_nlev; j->warps = h->last_warps; j->iters = h->last_iters; j->t0 = now_ms() - st.ms_total; j->finished = true;
     } else {
-        rc = queue_submit(h, j, mode, in0, in1, n_pairs, H, W, scale, flow_out, device);
+        rc = queue_submit(h, j, mode, in0, in1, n_pairs, H, W, scale, flow_out, device, false);
         if (rc) { delete j; return rc; }
     }
     *ticket = h->next_ticket++;
