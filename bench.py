@@ -35,11 +35,6 @@ import time
 
 import numpy as np
 
-# Before anything initialises HIP: a roomier pool of hardware queues than HIP's default 4, so that the engine's three lanes, their copy
-# streams and torch's streams do not share one (streams that share a hardware queue are serialised; the library also probes for this
-# when it makes its lanes -- `streams_serialised` in the line below says if it had to give up).  A caller's own setting is left alone.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -471,8 +466,9 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
     last_flow = flows[last_buf]
     queue_lanes = eng.counter("queue_lanes")
     units_per_step = (eng.counter("queue_units_done") - units0) / max(steps, 1) if (B > SUB or E > 1) else 1     # what the library cut a step into
-    lane_streams = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_tried_and_dropped": eng.counter("stream_retries"),
-                    "lanes_serialised_on_a_shared_hardware_queue": bool(eng.counter("streams_serialised"))}
+    lane_streams = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP's default: 4)"), "streams_tried_and_dropped": eng.counter("stream_retries"),
+                    "lanes_serialised_on_a_shared_hardware_queue": bool(eng.counter("streams_serialised") & 1),
+                    "copy_stream_shares_a_hardware_queue_with_a_solve_stream": bool(eng.counter("streams_serialised") & 2)}
     gather_ok = None
     if world > 1:
         # every rank's shard must have arrived intact everywhere: compare checksums of the gathered segments with the

@@ -38,12 +38,6 @@
 
 #define TF_API extern "C" __attribute__((visibility("default")))
 
-// HIP's default of 4 hardware queues per process makes the streams of a process share them, and work of streams that share one is
-// serialised (see streams_concurrent below).  The lanes probe for streams that run beside each other; a roomier pool makes the search
-// trivial and also keeps the lanes' copy streams off each other's queues.  Takes effect only if this library is loaded before the HIP
-// runtime initialises (it reads the variable once); a value the caller has set is left alone.
-__attribute__((constructor)) static void tf_hw_queue_default() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 namespace {
 
 constexpr int MAXLEV = 64;
@@ -193,11 +187,12 @@ struct tf_handle : TfKnobs {
     int queue_unit = 0;          // pairs per queue unit (0 = equal units of at most max_batch pairs, a multiple of the lane count of them)
     int queue_test_fail_unit = -1;   // tests: the lane that takes this unit of the next queued job reports a failure instead of solving it
     bool is_lane = false;        // this handle is a queue lane of another handle (an engine of its own: stream, buffers, host thread, its own twins)
+    tf_handle* owner = nullptr;  // ... of this one
     LanePool* pool = nullptr;
     long long q_jobs = 0, q_units_done = 0, q_units_skipped = 0, q_units_failed = 0;
     std::map<int, QJob*> tickets; int next_ticket = 1;      // tf_submit_* jobs not yet waited for
     int stream_retries = 0;      // streams made and dropped while looking for lane / twin streams that run beside each other (give_concurrent_stream)
-    int streams_serialised = 0;  // 1: a lane or twin had to keep a stream that shares a hardware queue with another one's
+    int streams_serialised = 0;  // bit 0: a lane or twin had to keep a solve stream that shares a hardware queue with a sibling's; bit 1: a lane's copy stream shares one with a solve stream
 };
 
 
@@ -1078,10 +1073,9 @@ int calc_common(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1,
         if (step < 16) step = 16;
         if (step > h->cap) step = h->cap;
     }
-    if (overlap && !h->copy_stream) {
-        HIPC(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (overlap && !h->copy_stream) HIPC(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (overlap && !h->cev[0])
         for (auto& e : h->cev) HIPC(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     const size_t flow_half = (size_t)step * npx * 2;          // floats per staging half
     if (!in_dev || !out_dev) {
         rc = ensure_staging(h, in_dev ? 0 : 2 * (size_t)h->cap * fpx, out_dev ? 0 : (overlap ? 2 : 1) * flow_half * sizeof(float));
@@ -1291,7 +1285,7 @@ int calc_split(tf_handle* h, Mode mode, const uint8_t* in0, const uint8_t* in1, 
         t->is_twin = true;
         std::vector<hipStream_t> others{h->own_stream};
         for (tf_handle* o : h->twins) others.push_back(o->own_stream);
-        if (!give_concurrent_stream(t, others, &h->stream_retries)) h->streams_serialised = 1;
+        if (!give_concurrent_stream(t, others, &h->stream_retries)) h->streams_serialised |= 1;
         h->twins.push_back(t);
     }
     const size_t npx = (size_t)H * W, fpx = npx * (h->src_f32 ? 4 : 1);      // fpx in bytes
@@ -1431,11 +1425,33 @@ int pool_ensure(tf_handle* h)
             delete pool;
             return fail(h, rc, "creating queue lane %d failed: %s", k + 1, tf_last_error(nullptr));
         }
-        t->is_lane = true;
+        t->is_lane = true; t->owner = h;
         std::vector<hipStream_t> others;
         for (tf_handle* o : pool->lanes) others.push_back(o->own_stream);
-        if (!give_concurrent_stream(t, others, &h->stream_retries)) h->streams_serialised = 1;
+        if (!give_concurrent_stream(t, others, &h->stream_retries)) h->streams_serialised |= 1;
         pool->lanes.push_back(t);
+    }
+    // A lane's copy-out (pinned host destinations: D2H of one unit under the next unit's solve) must run beside EVERY lane's solve, its own
+    // included: each lane gets a copy stream on a hardware queue none of the solve streams uses (all lanes are idle here; with HIP's four
+    // hardware queues that is the fourth one, which the copy streams then share among themselves -- PCIe is one resource anyway).
+    for (tf_handle* l : pool->lanes) {
+        std::vector<hipStream_t> rejected;
+        bool ok = false;
+        for (int k = 0; k < 8 && !ok; ++k) {
+            hipStream_t cs = nullptr;
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            ok = true;
+            for (tf_handle* o : pool->lanes) if (streams_concurrent(o->own_stream, cs) == 0) { ok = false; break; }
+            if (ok || k == 7) {
+                l->copy_stream = cs;
+                for (auto& e : l->cev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) (void)hipGetLastError();
+                if (!ok) h->streams_serialised |= 2;         // bit 1: a copy stream shares a hardware queue with a solve stream
+                break;
+            }
+            rejected.push_back(cs);
+            ++h->stream_retries;
+        }
+        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
     }
     h->pool = pool;
     for (tf_handle* l : pool->lanes) pool->th.emplace_back(lane_worker, h, pool, l);

@@ -211,7 +211,8 @@ eng.close()
 def test_lanes_look_for_streams_that_run_beside_each_other(queues):
     """HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues and serialises streams that share one.  With 8 or 4 queues the three
     lanes end up on streams that run concurrently (the probe may have to drop a few); with 2 they cannot, and the library says so
-    instead of assuming.  Flows do not depend on any of it."""
+    instead of assuming.  (The library leaves GPU_MAX_HW_QUEUES alone: with 8 the two-lane form of one-sub-batch calls measured 2276
+    against 2673 pairs/s -- DESIGN.md section 5a.)  Flows do not depend on any of it."""
     import json
     import os
     import subprocess
@@ -223,9 +224,11 @@ def test_lanes_look_for_streams_that_run_beside_each_other(queues):
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert g["lanes"] == 3 and g["same"]
     if queues == "2":
-        assert g["serialised"] == 1 and g["retries"] >= 8
+        assert g["serialised"] & 1 and g["retries"] >= 8
     else:
-        assert g["serialised"] == 0
+        assert g["serialised"] & 1 == 0
+    if queues == "8":
+        assert g["serialised"] == 0                                       # room for the lanes' copy streams too
     test_lanes_look_for_streams_that_run_beside_each_other.sums = getattr(test_lanes_look_for_streams_that_run_beside_each_other, "sums", set()) | {g["sum"]}
     assert len(test_lanes_look_for_streams_that_run_beside_each_other.sums) == 1
 

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--tuning", default="")
-    ap.add_argument("--k", type=int, default=2, help="iterations per launch of the form under test (3 for iter_variant=6)")
+    ap.add_argument("--k", type=int, default=2, help="iterations per launch of the form under test")
     ap.add_argument("--lanes", type=int, default=1)
     a = ap.parse_args()
     import torch

@@ -137,8 +137,8 @@ def main():
             dt, (f, n) = timed(form_d, a.steps, P)
             same = np.array_equal(f.cpu().numpy(), ref) and (a.distinct or np.array_equal(big[P - B:P].cpu().numpy(), ref))
             print(f"  d  one engine, ONE synchronous call per {P:5d} pairs   : {n / dt:7.1f} pairs/s  identical {same}")
-    print(f"  lane / twin streams: tried and dropped {one.counter('stream_retries')}, serialised on a shared hardware queue: {bool(one.counter('streams_serialised'))}, "
-          f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
+    print(f"  lane / twin streams: tried and dropped {one.counter('stream_retries')}, solve streams serialised on a shared hardware queue: {bool(one.counter('streams_serialised') & 1)}, "
+          f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'unset (4)')}")
     one.close()
     for e in three:
         e.close()
