@@ -1437,12 +1437,12 @@ int pool_ensure(tf_handle* h)
     for (tf_handle* l : pool->lanes) {
         std::vector<hipStream_t> rejected;
         bool ok = false;
-        for (int k = 0; k < 8 && !ok; ++k) {
+        for (int k = 0; k < 5 && !ok; ++k) {
             hipStream_t cs = nullptr;
             if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
             ok = true;
             for (tf_handle* o : pool->lanes) if (streams_concurrent(o->own_stream, cs) == 0) { ok = false; break; }
-            if (ok || k == 7) {
+            if (ok || k == 4) {
                 l->copy_stream = cs;
                 for (auto& e : l->cev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) (void)hipGetLastError();
                 if (!ok) h->streams_serialised |= 2;         // bit 1: a copy stream shares a hardware queue with a solve stream
