@@ -271,3 +271,34 @@ def test_queue_stress_random_jobs_random_collection_order(algo, cap):
     finally:
         eng.close()
         ref.close()
+
+
+def test_studies_through_the_queue_device_frames_host_flows(oracle):
+    """tf_calc_seq_rgb / tf_submit_seq_rgb / tf_calc_seq_saliency_f32 on studies longer than a sub-batch: the frames are conditioned (or turned
+    into saliency maps) on the device, the lanes read their units from that device buffer and copy their flows to the caller's host array."""
+    import tee_optical_flow_amd as T
+    from tee_optical_flow_amd.frames import condition_frames
+    from tee_optical_flow_amd.synth import speckle_sequence
+    studies = [np.ascontiguousarray(np.repeat(speckle_sequence(60 + k, n, 72, 104)[..., None], 3, axis=3)) for k, n in enumerate((30, 12, 41))]
+    eng = T.DenseFlow(device_id=0, max_batch=8)
+    try:
+        want = []
+        for rgb in studies:
+            eng.set_tuning("queue_lanes", 0)
+            want.append(np.array(eng.calc_batch(condition_frames(rgb), scale=1.25)))
+        eng.set_tuning("queue_lanes", -1)
+        for rgb, w in zip(studies, want):
+            got = np.array(eng.calc_study(rgb, scale=1.25, pad_last=True))
+            assert got.shape[0] == rgb.shape[0] and np.array_equal(got[:-1], w) and np.array_equal(got[-1], got[-2])
+        tickets = [eng.submit_study(rgb, scale=1.25, pad_last=(k == 1)) for k, rgb in enumerate(studies)]
+        studies[0][...] = 0                                                # the frames were conditioned at submission: the caller's array is free
+        for k in (2, 0, 1):
+            got = np.array(eng.wait(tickets[k]))
+            assert np.array_equal(got[:want[k].shape[0]], want[k]), f"study {k}"
+            assert got.shape[0] == want[k].shape[0] + (1 if k == 1 else 0)
+        assert np.array_equal(want[1][3], oracle.tvl1_calc(condition_frames(studies[1])[3], condition_frames(studies[1])[4]) * np.float32(1.25))
+        sal = np.array(eng.calc_study_saliency(studies[2], scale=2.0))     # 40 pairs in sub-batches of 8, float maps
+        maps = eng.saliency_frames(studies[2])
+        assert np.array_equal(sal, np.array(eng.calc_pairs(maps[:-1], maps[1:])) * np.float32(2.0))
+    finally:
+        eng.close()
