@@ -283,9 +283,11 @@ def test_studies_through_the_queue_device_frames_host_flows(oracle):
     eng = T.DenseFlow(device_id=0, max_batch=8)
     try:
         want = []
-        for rgb in studies:
+        grays = [eng.condition_frames(rgb) for rgb in studies]             # the device's conditioning (the host twin goes through numpy's matmul,
+        assert sum(int((g != condition_frames(rgb)).sum()) for g, rgb in zip(grays, studies)) <= 3      # whose BLAS may fuse: a count off on a rare pixel)
+        for g in grays:
             eng.set_tuning("queue_lanes", 0)
-            want.append(np.array(eng.calc_batch(condition_frames(rgb), scale=1.25)))
+            want.append(np.array(eng.calc_batch(g, scale=1.25)))
         eng.set_tuning("queue_lanes", -1)
         for rgb, w in zip(studies, want):
             got = np.array(eng.calc_study(rgb, scale=1.25, pad_last=True))
@@ -296,7 +298,7 @@ def test_studies_through_the_queue_device_frames_host_flows(oracle):
             got = np.array(eng.wait(tickets[k]))
             assert np.array_equal(got[:want[k].shape[0]], want[k]), f"study {k}"
             assert got.shape[0] == want[k].shape[0] + (1 if k == 1 else 0)
-        assert np.array_equal(want[1][3], oracle.tvl1_calc(condition_frames(studies[1])[3], condition_frames(studies[1])[4]) * np.float32(1.25))
+        assert np.array_equal(want[1][3], oracle.tvl1_calc(grays[1][3], grays[1][4]) * np.float32(1.25))
         sal = np.array(eng.calc_study_saliency(studies[2], scale=2.0))     # 40 pairs in sub-batches of 8, float maps
         maps = eng.saliency_frames(studies[2])
         assert np.array_equal(sal, np.array(eng.calc_pairs(maps[:-1], maps[1:])) * np.float32(2.0))
