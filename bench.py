@@ -828,6 +828,12 @@ def main():
         raise SystemExit(rc)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        # N > 1: the all-gather of step k runs on the engine's communication stream beside step k+1's solve.  With HIP's four hardware
+        # queues every queue a created stream can get is already one of the three lanes', and a collective kernel that shares a lane's
+        # queue would hold that lane up while it waits for its peers; eight queues give the communication stream (and RCCL's own) room.
+        # (Single-GPU runs leave the default: eight queues slow the latency-bound forms)  Before torch touches HIP.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     # ---- CPU-only preparation: nothing below this block may start a process ------------------------------------
     if a.batch is None:
