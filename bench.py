@@ -765,6 +765,21 @@ def run_leg(a, algo, B, steps, warmup, I0s, I1s, torch, dist, dev, rank, world, 
         tp = time.perf_counter()
         eng.calc_pairs(I0s, I1s)
         out["pcie_inclusive_pairs_per_s"] = B / (time.perf_counter() - tp)
+        if algo == "TVL1":
+            # the same with two calls in flight (tf_submit_pairs): one call's copy-out runs under the next call's solve
+            for _ in range(2):                          # the pinned pool then holds two result buffers
+                tk = [eng.submit_pairs(I0s, I1s), eng.submit_pairs(I0s, I1s)]
+                res = [eng.wait(t) for t in tk]
+                del res
+            tp = time.perf_counter()
+            tk, n_calls = [], 6
+            for _ in range(n_calls):
+                if len(tk) == 2:
+                    eng.wait(tk.pop(0))
+                tk.append(eng.submit_pairs(I0s, I1s))
+            while tk:
+                eng.wait(tk.pop(0))
+            out["pcie_inclusive_pairs_per_s_two_calls_in_flight"] = n_calls * B / (time.perf_counter() - tp)
         if world == 1 and not a.no_cpu_baseline:
             n = min(cpu_sample, B)
             cb, ref = cpu_baseline(I0s, I1s, n, algo)
