@@ -305,17 +305,25 @@ __global__ __launch_bounds__(64 * NB) void k_df_sor_rt(DfBufs d, Geom g, float o
 //     word in its own wait and leaves too; the host then repeats the solve with the tiled form.  (Cannot happen while the grid fits
 //     the CUs this handle was given; a second process on the same GPU can make it happen.)
 // Bit-identical to the tiled form by construction: same regions, same halo, same sweeps.
+// The pointers reach these helpers through a run-time choice between the two (du, dv) buffers, which makes hipcc forget that they are
+// global memory and emit flat_load / flat_store.  The hand-off this exchange relies on is documented for global_ / buffer_ `sc1` accesses
+// only (MI355X_MICROARCH.md, inter-workgroup visibility: "never flat_"), so the address space is stated.
+typedef __attribute__((address_space(1))) unsigned long long rt_gu64;
+typedef __attribute__((address_space(1))) float rt_gf32;
+typedef __attribute__((address_space(1))) unsigned rt_gu32;
 __device__ __forceinline__ float2 rt_ld_sc1(const float* p)
 {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load((const rt_gu64*)(const void*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 __device__ __forceinline__ void rt_st_sc1(float* p, float a, float b)
 {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
+    __hip_atomic_store((rt_gu64*)(void*)p, (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void rt_st_sc1(float* p, float a) { __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rt_st_sc1(float* p, float a) { __hip_atomic_store((rt_gf32*)(void*)p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned rt_ld_flag(const unsigned* p) { return __hip_atomic_load((const rt_gu32*)(const void*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rt_st_flag(unsigned* p, unsigned v) { __hip_atomic_store((rt_gu32*)(void*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #ifdef TF_COOP_TIMING
 __device__ unsigned long long g_coop_t[4][64];      // [block sample][event]: s_memrealtime (100 MHz) stamps of wave 0
@@ -370,7 +378,7 @@ __device__ __forceinline__ void sor_rt_coop_phases(SorRtState<R, NB>& t, float2 
         COOP_TE();
         if (wv == 0) {
             const unsigned target = base + (unsigned)phase;
-            if (ln == 0 && !(mute && me == 0)) __hip_atomic_store(flags + (size_t)me * 32, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ln == 0 && !(mute && me == 0)) rt_st_flag(flags + (size_t)me * 32, target);
             const int q = ln < 9 ? ln : 4;
             const int nx = (int)blockIdx.x + q % 3 - 1, ny = (int)blockIdx.y + q / 3 - 1;
             const bool ex = nx >= 0 && nx < (int)gridDim.x && ny >= 0 && ny < (int)gridDim.y;
@@ -379,14 +387,14 @@ __device__ __forceinline__ void sor_rt_coop_phases(SorRtState<R, NB>& t, float2 
             bool ok;
             unsigned ab;
             while (true) {
-                const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ab = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned v = rt_ld_flag(f);
+                ab = rt_ld_flag(abort_word);
                 ok = __all((int)(v - target) >= 0) != 0;
                 if (ok || ab != 0 || ++polls > RT_COOP_POLL_LIMIT) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             if (!ok && ln == 0) {
-                if (ab == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ab == 0) rt_st_flag(abort_word, 1u);
                 *gone = 1;
             }
         }
