@@ -42,37 +42,37 @@ def main():
     P.process_folder(src, os.path.join(tmp, "warm2"), None, process_subset=True, file_subset_list=["study00.npz", "study01.npz"], workers=workers, **kw)
     # where the caller's thread spends a study in the worker-process walk: solve (flow_for_study), hand-over to the writer (defer),
     # the rest of process_video, and everything outside it (waiting for the reader stage, reaping writers)
-    acc = {"video": 0.0, "flow": 0.0, "defer": 0.0}
-    real_pv, real_ffs = P.process_video, P.flow_for_study
+    acc = {"begin": 0.0, "finish": 0.0, "defer": 0.0}
+    real_begin = P._process_video_begin
 
-    def timed_ffs(*args, **kwargs):
-        t = time.perf_counter()
-        try:
-            return real_ffs(*args, **kwargs)
-        finally:
-            acc["flow"] += time.perf_counter() - t
-
-    def timed_pv(*args, **kwargs):
+    def timed_begin(*args, **kwargs):
         d = kwargs.get("_defer_save")
         if d is not None:
             def timed_defer(job):
                 t = time.perf_counter(); d(job); acc["defer"] += time.perf_counter() - t
             kwargs["_defer_save"] = timed_defer
         t = time.perf_counter()
-        try:
-            return real_pv(*args, **kwargs)
-        finally:
-            acc["video"] += time.perf_counter() - t
+        fin = real_begin(*args, **kwargs)                   # masks are ready; conditions the frames and SUBMITS the solve (studies_in_flight=2)
+        acc["begin"] += time.perf_counter() - t
+
+        def timed_finish():
+            t2 = time.perf_counter()
+            try:
+                return fin()                                # waits for the flows, hands the study to the writer stage
+            finally:
+                acc["finish"] += time.perf_counter() - t2
+        return timed_finish
     if a.stages:
-        P.process_video, P.flow_for_study = timed_pv, timed_ffs
+        P._process_video_begin = timed_begin
     t0 = time.perf_counter()
     errs_p = P.process_folder(src, os.path.join(tmp, "processes"), None, workers=workers, **kw)
     t_proc = time.perf_counter() - t0
-    P.process_video, P.flow_for_study = real_pv, real_ffs
+    P._process_video_begin = real_begin
     if a.stages:
         n = a.studies
-        print(f"  caller's thread per study (worker-process walk): solve {acc['flow'] / n * 1e3:.1f} ms, hand-over to the writer {acc['defer'] / n * 1e3:.1f} ms, "
-              f"rest of process_video {(acc['video'] - acc['flow'] - acc['defer']) / n * 1e3:.1f} ms, outside it (reader wait, reaping) {(t_proc - acc['video']) / n * 1e3:.1f} ms")
+        print(f"  caller's thread per study (worker-process walk, the next study's solve submitted before this one's is collected): submit (conditioning "
+              f"+ queueing) {acc['begin'] / n * 1e3:.1f} ms, collect + hand-over {acc['finish'] / n * 1e3:.1f} ms (of which hand-over to the writer {acc['defer'] / n * 1e3:.1f} ms), "
+              f"outside both (reader wait, reaping) {(t_proc - acc['begin'] - acc['finish']) / n * 1e3:.1f} ms")
     workers.close()
     t0 = time.perf_counter()
     errs = P.process_folder(src, os.path.join(tmp, "overlapped"), None, workers="thread", **kw)
