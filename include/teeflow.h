@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 2   /* 2: tf_stats grew the per-stage times ms_warp .. ms_sched */
+#define TF_ABI_VERSION 2   /* 2: tf_stats grew the per-stage times ms_warp .. ms_sched.  Round 5 ADDED entry points (tf_submit_*, tf_wait,
+                              tf_saliency_frames_f32, tf_calc_seq_saliency_f32) and changed no struct and no signature: still 2 */
 
 enum {
     TF_OK = 0,

@@ -311,3 +311,75 @@ def test_unguarded_script_with_a_picklable_reader_is_detected(tmp_path):
     g = json.loads(r.stdout.strip().splitlines()[-1])
     assert g["errors"] == [] and g["files"] == ["s0.hdf5", "s1.hdf5", "s2.hdf5"], g
     assert any("outside an `if __name__ == '__main__':` block" in w for w in g["warnings"]), g["warnings"]
+
+
+ASYNC_DRIVER = r"""
+import sys, json, os, numpy as np
+sys.path.insert(0, ROOT)
+import h5py
+from tee_optical_flow_amd.pipeline import process_folder
+from tee_optical_flow_amd.synth import speckle_sequence
+
+class AsyncFake:                        # stands in for DenseFlow's study calls (tests only): submit_study / wait like the engine's
+    device_unit_scale = True
+    def __init__(self): self.log, self.jobs, self.n = [], {}, 0
+    def _flow(self, rgb, scale, pad_last):
+        g = rgb[..., 0].astype(np.float32)
+        d = (g[1:] - g[:-1]) / 64
+        f = np.stack([d, -0.5 * d], -1) * np.float32(scale)
+        return np.concatenate([f, f[-1:]]) if pad_last else f
+    def calc_study(self, rgb, scale=1.0, pad_last=False):
+        self.log.append(("calc", rgb.shape[1]))
+        if rgb.shape[1] == 40: raise RuntimeError("solver failure injected for 40-row studies")
+        return self._flow(rgb, scale, pad_last)
+    def submit_study(self, rgb, scale=1.0, pad_last=False):
+        self.n += 1
+        self.log.append(("submit", rgb.shape[1]))
+        self.jobs[self.n] = (rgb.copy(), scale, pad_last)
+        return self.n
+    def wait(self, t):
+        rgb, scale, pad_last = self.jobs.pop(t)
+        self.log.append(("wait", rgb.shape[1]))
+        if rgb.shape[1] == 40: raise RuntimeError("solver failure injected for 40-row studies")
+        return self._flow(rgb, scale, pad_last)
+    def close(self): pass
+
+src = os.path.join(TMP, "in"); os.makedirs(src)
+rows = [48, 40, 56, 64, 72]                                 # study 1 fails in its solve; every study has its own height, so the log names it
+for k, h in enumerate(rows):
+    g = speckle_sequence(400 + k, 5, h, 64)
+    np.savez(os.path.join(src, f"s{k}.npz"), nparr=np.repeat(g[..., None], 3, axis=3), pixel_spacing=0.05, frame_rate=40.0)
+out = {}
+for depth in (2, 1, 3):
+    m = AsyncFake()
+    errs = process_folder(src, os.path.join(TMP, f"out{depth}"), None, nchunks=1, chunk_index=0, mode="otsu", verbose=False, extensions=("npz",),
+                          flow_model=m, workers="thread", no_saliency=True, studies_in_flight=depth)
+    out[str(depth)] = {"errors": errs, "files": sorted(os.listdir(os.path.join(TMP, f"out{depth}"))), "log": m.log, "left": len(m.jobs)}
+same = True
+for k in (0, 2, 3, 4):
+    with h5py.File(os.path.join(TMP, "out2", f"s{k}.hdf5"), "r") as a, h5py.File(os.path.join(TMP, "out1", f"s{k}.hdf5"), "r") as b:
+        same &= all(bool(np.array_equal(a[key][...], b[key][...])) for key in a.keys())
+out["same"] = bool(same)
+print(json.dumps(out, default=str))
+"""
+
+
+def test_process_folder_keeps_the_next_solve_in_flight_and_blames_the_right_study(tmp_path):
+    """studies_in_flight=2: study k+1's solve is SUBMITTED before study k's flows are collected (submit, submit, wait, submit, wait, ...); a
+    solve that fails when it is collected is reported under ITS file name and costs no other study; depth 1 solves study by study through
+    the synchronous call; the files are the same either way; nothing stays submitted."""
+    if not os.path.exists(PY_H5):
+        pytest.skip("no interpreter with h5py")
+    script = tmp_path / "async.py"
+    script.write_text(ASYNC_DRIVER.replace("ROOT", repr(ROOT)).replace("TMP", repr(str(tmp_path))))
+    r = subprocess.run([PY_H5, str(script)], capture_output=True, text=True, timeout=300, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = json.loads(r.stdout.strip().splitlines()[-1])
+    for depth in ("2", "1", "3"):
+        assert [e[0] for e in g[depth]["errors"]] == ["s1.npz"] and "injected" in g[depth]["errors"][0][1], g[depth]["errors"]
+        assert g[depth]["files"] == ["s0.hdf5", "s2.hdf5", "s3.hdf5", "s4.hdf5"] and g[depth]["left"] == 0
+    assert g["same"]
+    assert g["2"]["log"] == [["submit", 48], ["submit", 40], ["wait", 48], ["submit", 56], ["wait", 40], ["submit", 64], ["wait", 56],
+                             ["submit", 72], ["wait", 64], ["wait", 72]]
+    assert g["1"]["log"] == [["calc", h] for h in (48, 40, 56, 64, 72)]
+    assert g["3"]["log"][:4] == [["submit", 48], ["submit", 40], ["submit", 56], ["wait", 48]]
