@@ -771,6 +771,11 @@ def process_folder(dcm_folder, save_folder, segmentor_model=None, nchunks=10, ch
                 begun_ref[0].popleft()[2]()
             except Exception:
                 pass
+        for _path, fut in pending:                                    # (same case) writers still at work keep their study's blocks until done
+            try:
+                fut.result()
+            except Exception:
+                pass
         for k, fut in futs.items():                                   # reader results nobody took (an exception above): free their blocks
             try:
                 res = fut.result()
