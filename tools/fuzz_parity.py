@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity: random sizes, batch sizes and DualTVL1 parameters (all the cv2 setters the engine
-supports), flows and executed iteration counts compared bit for bit.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+supports), flows and executed iteration counts compared bit for bit.  usage: python tools/fuzz_parity.py [cases] [seed] [big]
+("big": sizes 161..640 x 201..800 instead of 5..160 x 5..200, fewer pairs per case -- the oracle takes about a second per pair there)"""
 import os
 import sys
 import time
@@ -13,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     import tee_optical_flow_amd as T
     from oracle import oracle as O
     from tee_optical_flow_amd.synth import speckle_pairs
@@ -21,6 +23,8 @@ def main():
     t0 = time.time()
     for c in range(cases):
         H = int(rng.integers(5, 161)); W = int(rng.integers(5, 201)); B = int(rng.choice([1, 2, 3, 7, 20, 40, 70]))
+        if big:
+            H = int(rng.integers(161, 641)); W = int(rng.integers(201, 801)); B = int(rng.choice([1, 2, 9, 20, 33]))
         p = dict(tau=float(rng.choice([0.25, 0.2, 0.1])), lambda_=float(rng.choice([0.15, 0.05, 0.3, 1.0])),
                  theta=float(rng.choice([0.3, 0.2, 0.5])), nscales=int(rng.integers(1, 7)), warps=int(rng.integers(1, 6)),
                  epsilon=float(rng.choice([0.01, 0.02, 0.005, 0.05])), inner_iterations=int(rng.choice([30, 10, 7, 2, 1, 16, 9, 3, 12])),
