@@ -306,3 +306,35 @@ def test_studies_through_the_queue_device_frames_host_flows(oracle):
         assert np.array_equal(sal, np.array(eng.calc_pairs(maps[:-1], maps[1:])) * np.float32(2.0))
     finally:
         eng.close()
+
+
+def _threads_now():
+    with open("/proc/self/status") as f:
+        return int(next(ln for ln in f if ln.startswith("Threads:")).split()[1])
+
+
+def test_engines_with_lanes_give_back_their_device_memory_and_threads():
+    """tf_destroy ends the lanes (host threads, streams, device buffers, jobs never waited for): handles made and closed in a loop
+    leave the device's free memory and the process's thread count where the first round left them."""
+    import torch
+    from tee_optical_flow_amd.synth import speckle_sequence
+    I0s, I1s = _mixed(20, 64, 80)
+    rgb = np.repeat(speckle_sequence(5, 7, 64, 80)[..., None], 3, axis=-1)
+    free, threads = [], []
+    for rnd in range(7):
+        for algo in ("TVL1", "deepflow"):
+            eng = _engine(8, algo=algo)
+            eng.calc_pairs(I0s, I1s)                                      # three units on the lanes (DeepFlow: one lane, its twin)
+            assert eng.counter("queue_jobs") == 1
+            t1 = eng.submit_pairs(I0s[:9], I1s[:9])
+            t2 = eng.submit_pairs(I0s[9:], I1s[9:])
+            eng.wait(t2)                                                  # t1 is never waited for: close() owns it
+            if algo == "TVL1":
+                eng.calc_study_saliency(rgb, scale=1.0)
+            del t1
+            eng.close()
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info(0)[0])
+        threads.append(_threads_now())
+    assert max(threads[1:]) <= threads[1] + 1, threads                    # (round 0 starts the runtime's own threads)
+    assert min(free[2:]) >= free[1] - (8 << 20), [f >> 20 for f in free]  # MiB free after each round
