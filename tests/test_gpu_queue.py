@@ -316,8 +316,14 @@ def _threads_now():
 def test_engines_with_lanes_give_back_their_device_memory_and_threads():
     """tf_destroy ends the lanes (host threads, streams, device buffers, jobs never waited for): handles made and closed in a loop
     leave the device's free memory and the process's thread count where the first round left them."""
-    import torch
+    import ctypes
     from tee_optical_flow_amd.synth import speckle_sequence
+    hip = ctypes.CDLL("libamdhip64.so")                                   # (already in the process: the library links it; torch stays out of this test)
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
     I0s, I1s = _mixed(20, 64, 80)
     rgb = np.repeat(speckle_sequence(5, 7, 64, 80)[..., None], 3, axis=-1)
     free, threads = [], []
@@ -333,8 +339,7 @@ def test_engines_with_lanes_give_back_their_device_memory_and_threads():
                 eng.calc_study_saliency(rgb, scale=1.0)
             del t1
             eng.close()
-        torch.cuda.synchronize()
-        free.append(torch.cuda.mem_get_info(0)[0])
+        free.append(free_bytes())
         threads.append(_threads_now())
     assert max(threads[1:]) <= threads[1] + 1, threads                    # (round 0 starts the runtime's own threads)
     assert min(free[2:]) >= free[1] - (8 << 20), [f >> 20 for f in free]  # MiB free after each round
